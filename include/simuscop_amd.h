@@ -1,0 +1,157 @@
+/* simuscop_amd.h -- C ABI of the MI355X read-sampling engine (libsimuscop_amd.so).
+ *
+ * The reference (SimuSCoP v1.0) has no FFI/plugin interface; its only seam on this path is the C
+ * work item handed to the thread pool,
+ *     threadPool->pool_add_work(&Segment::yieldReads, &chrSegs[k], n++)   lib/genome/Genome.cpp:881,949
+ *     void* (*)(const void* arg)                                          lib/threadpool/ThreadPool.h:195
+ * executed once per <=1 Mbp segment between generateSegSequences() (Genome.cpp:876-878) and
+ * threadPool->wait() (:883).  This library replaces that whole per-chromosome block -- every
+ * Segment::yieldReads call of one (population, chromosome), including Profile::predict,
+ * Profile::yieldInsertSize, Segment::getFragSequence / Genome::produceFragment and the FASTQ
+ * formatting -- by one batched GPU pass.  What crosses the boundary is exactly the state those
+ * functions read: the Profile CDF tables, the haplotype strings, and the per-window sampling plan.
+ * INTEGRATION.md shows the binding a SimuSCoP maintainer would add.
+ *
+ * Plain C, no torch / HIP types in signatures.  One sg_ctx per GPU; a ctx is thread-compatible
+ * (use it from one host thread at a time).  All functions return SG_OK (0) or an error code;
+ * sg_last_error() gives the message (the reference prints to cerr and exit(1)s instead,
+ * e.g. lib/config/Config.cpp:67-70 -- the CLI layer maps a non-zero status to that behaviour).
+ */
+#ifndef SIMUSCOP_AMD_H
+#define SIMUSCOP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK 0
+#define SG_ERR_INVALID 1     /* bad argument / call order            */
+#define SG_ERR_HIP 2         /* HIP runtime error (no GPU, OOM, ...) */
+#define SG_ERR_UNSUPPORTED 3 /* profile shape outside the kernels' range (bases != 4, kmer > 6 ...) */
+#define SG_ERR_OVERFLOW 4    /* more than SG_MAX_EVENTS sequencing indels in one read             */
+
+#define SG_MAX_EVENTS 8
+
+typedef struct sg_ctx sg_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* Replaces `threadPool = new ThreadPool(threads); pool_init()` (src/simuReads.cpp:63-64,
+ * lib/threadpool/ThreadPool.cpp:8-51): one context per GPU instead of N pinned pthreads, and one
+ * 64-bit seed instead of clock-seeded mt19937 pairs (ThreadPool.cpp:41-49).                      */
+int sg_create(sg_ctx** ctx, int device, uint64_t seed);
+void sg_destroy(sg_ctx* ctx);
+const char* sg_last_error(const sg_ctx* ctx); /* ctx may be NULL: error of a failed sg_create */
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
+int sg_set_stream(sg_ctx* ctx, void* hip_stream);
+int sg_set_seed(sg_ctx* ctx, uint64_t seed);
+
+/* ---- profile tables ---------------------------------------------------------------------- */
+/* The products of Profile::train(file) (lib/profile/Profile.cpp:1436-1440) exactly as the
+ * reference holds them in memory: fp64 cumulative tables (Matrix<double>::getEntrance() rows,
+ * Profile.cpp:1367-1434).  The library converts them to exact u32 thresholds of the reference's
+ * 32-bit uniform (lib/threadpool/ThreadPool.cpp:203-207, lib/mydefine/MyDefine.cpp:176-184).   */
+typedef struct sg_profile_cdf {
+  int32_t n_bases;          /* config "bases" length, must be 4        Profile.cpp:1000 */
+  char bases[8];            /* e.g. "ACTG"                                               */
+  int32_t kmer;             /* Profile.cpp:1001                                           */
+  int32_t bins;             /* Profile.cpp:1002 (already clipped to read_length, :185)    */
+  int32_t read_length;      /* Profile.cpp:1003                                           */
+  int32_t n_qual;           /* maxBaseQuality-minBaseQuality+1 = 94, Profile.cpp:208      */
+  int32_t min_qual;         /* 33, Profile.cpp:173                                        */
+  double insert_rate;       /* Profile::insertRate                                        */
+  double del_rate;          /* Profile::delRate                                           */
+  const double* ins_cdf;    /* insCdf  [n_ins]                         Profile.cpp:1375   */
+  int32_t n_ins;
+  const double* del_cdf;    /* delCdf  [n_del]                         Profile.cpp:1378   */
+  int32_t n_del;
+  const double* subs_cdf1;  /* subsCdf1[kmer_count][bins][n_bases]     Profile.cpp:1419   */
+  const double* subs_cdf2;  /* subsCdf2 or NULL (SE / stdISize<=0)     Profile.cpp:1420-1430 */
+  const double* qual_cdf;   /* qualityCdf[n_bases*n_bases][bins][n_qual] Profile.cpp:1398 */
+  const double* isize_cdf;  /* iSizeCdf[n_isize] or NULL -> fixed insert size, Profile.cpp:1487 */
+  int32_t n_isize;
+  int32_t isize_min;        /* iSizeAlphabet[0] (alphabet is consecutive, Profile.cpp:919-922) */
+  int32_t insert_size;      /* config insertSize (used when isize_cdf == NULL)            */
+} sg_profile_cdf;
+int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* prof);
+
+/* ---- haplotypes of one (population, chromosome) ------------------------------------------- */
+/* chain h = concatenation over the chromosome's segments, in order, of Segment::segSequences[h]
+ * (lib/segment/Segment.cpp:448-458; NULL entries contribute nothing).  A fragment that runs past
+ * its segment continues into the following segments' same-index haplotype
+ * (Segment::getFragSequence :1085-1101 -> Genome::produceFragment, Genome.cpp:599-632): on a chain
+ * that is a plain substring, clipped at the chain end.  Bytes are upper-case ASCII.             */
+int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chains, const uint64_t* lens);
+
+/* ---- sampling plan ------------------------------------------------------------------------ */
+/* One entry per sampling window of every processed segment (Segment.cpp:675 skips segments with no
+ * sequences or readCount == 0), i.e. Segment::fragStartPos / fragEndPos / hapIndxs / fragRCs
+ * (Segment.h:45-49) flattened in segment order, window order.                                   */
+typedef struct sg_window {
+  uint64_t hap_base;  /* offset of this segment's haplotype string inside chain `chain`        */
+  uint32_t chain;     /* hapIndxs[i]                                                            */
+  uint32_t spos;      /* fragStartPos[i]                                                        */
+  uint32_t len;       /* fragEndPos[i]-fragStartPos[i]+1                                        */
+  int32_t n_reads;    /* fragRCs[i]  (PE: ceil(n/2) pairs are produced, Segment.cpp:848)        */
+  uint32_t seg;       /* ordinal of the segment inside this batch                               */
+  uint32_t slot_base; /* exclusive prefix sum of planned pairs over the batch's windows         */
+} sg_window;
+
+typedef struct sg_batch {
+  uint32_t batch_id;          /* running index of (mixture, population, chromosome) batches      */
+  int32_t paired;             /* Config::isPairedEnd()                                            */
+  const char* name_prefix;    /* "@<popu>#<chr>#"  (Segment.cpp:780,809)                          */
+  const sg_window* windows;
+  uint64_t n_windows;
+  const uint32_t* seg_size;   /* per segment: seqSize/CN (Segment.cpp:713-714), for pos%segsize   */
+  const uint32_t* seg_first_window; /* per segment: index of its first window; [n_segs] = n_windows */
+  uint32_t n_segs;
+  /* Sharding: when a batch is split over several GPUs by runs of segments, each shard passes the
+   * index of its first window / first fragment slot inside the WHOLE batch, so that every draw keeps
+   * the address it has in the unsharded run (the shards' FASTQ concatenate to the 1-GPU output).
+   * windows[].slot_base stays shard-local (starts at 0).  Both 0 for an unsharded batch.           */
+  uint32_t first_window;
+  uint32_t first_slot;
+} sg_batch;
+int sg_plan(sg_ctx* ctx, const sg_batch* batch);
+
+/* ---- run ----------------------------------------------------------------------------------- */
+/* Enqueue the whole pass (plan draws, indel pass, offset scan, base/quality sampling + FASTQ
+ * formatting) for the planned batch.  Results stay in device memory.                            */
+int sg_sample(sg_ctx* ctx);
+/* Wait for the pass and report sizes: FASTQ bytes for mate 1 / mate 2 (0 for SE) and the number
+ * of fragments actually produced (pairs for PE, reads for SE).                                   */
+int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_fragments);
+/* Copy the FASTQ text to host buffers (the bytes SeqWriter::write(char*,char*) would receive,
+ * lib/seqwriter/SeqWriter.cpp:41-54).  host_r2 may be NULL for SE.                               */
+int sg_fetch(sg_ctx* ctx, char* host_r1, char* host_r2);
+/* Device pointers of the FASTQ text (valid until the next sg_sample / sg_plan).                  */
+int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2);
+
+/* ---- GC-window scan (Segment::getWeightedLength byte scan, Segment.cpp:563-592) ------------- */
+/* For every window [start, start+len) of chain `chain`: integer GC% = 100*GC/len, or -1 if the
+ * window holds any 'N' (lib/mydefine/MyDefine.cpp:279-303).  Uses the uploaded haplotypes.       */
+typedef struct sg_gc_window { uint64_t start; uint32_t chain; uint32_t len; } sg_gc_window;
+int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t* gc_out);
+
+/* ---- instrumentation ----------------------------------------------------------------------- */
+#define SG_K_PLAN 0
+#define SG_K_NAMEBASE 1
+#define SG_K_INDEL 2
+#define SG_K_SCAN 3
+#define SG_K_EMIT 4
+#define SG_K_COUNT 5
+/* When enabled, HIP events bracket every kernel of sg_sample on the ctx's stream;
+ * sg_kernel_times() then returns the last pass's per-kernel milliseconds (after sg_result).     */
+int sg_set_profiling(sg_ctx* ctx, int enable);
+int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
+
+/* Exact u32 form of the reference's inverse-CDF draw, exposed for tests: number of 32-bit draws
+ * x for which randIndx's `r <= c` holds (r = 2.2204e-16 + (1-2.2204e-16)*x/2^32).               */
+uint64_t sg_cdf_count_le(double c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

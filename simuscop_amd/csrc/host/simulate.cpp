@@ -1,0 +1,375 @@
+// host/simulate.cpp -- the `simuReads <config>` driver (src/simuReads.cpp:24-87 +
+// Genome::yieldReads, lib/genome/Genome.cpp:827-960) on top of the C ABI.
+//
+// Order of work per population:
+//   pass 1  for every chromosome: build haplotype chains once (host), upload, GC% per window on the
+//           GPU (sg_gc_percent), GC-bias weights and weighted lengths on the host in fp64 -- the read
+//           apportioning truncates fp64 products, so it stays where the reference computes it;
+//   counts  chromosome / segment / window read counts (Genome::setReadCounts, Segment::setReadCount);
+//   pass 2  one GPU batch per chromosome: sg_plan -> sg_sample -> sg_fetch -> FASTQ files.
+#include "simulate.h"
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <memory>
+
+#include "../../../include/simuscop_amd.h"
+#include "genome.h"
+
+namespace simu {
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+struct Engine {  // RAII around sg_ctx, turns status codes into simu::Error
+  sg_ctx* ctx = nullptr;
+  ~Engine() { if (ctx) sg_destroy(ctx); }
+  void check(int rc, const char* what) {
+    if (rc != SG_OK) throw Error(std::string("GPU engine error in ") + what + ": " + sg_last_error(ctx));
+  }
+};
+
+struct Sink {  // FASTQ output: <output>/<stem>_1.fq + _2.fq, or <stem>.fq (Genome.cpp:857-866)
+  FILE* f1 = nullptr;
+  FILE* f2 = nullptr;
+  void open(const std::string& dir, const std::string& stem, bool paired, const std::string& suffix) {
+    close();
+    if (paired) {
+      std::string a = dir + "/" + stem + "_1.fq" + suffix, b = dir + "/" + stem + "_2.fq" + suffix;
+      f1 = fopen(a.c_str(), "wb");
+      if (!f1) throw Error("Error: can not open fastq file to save results:\n" + a, -1);
+      f2 = fopen(b.c_str(), "wb");
+      if (!f2) throw Error("Error: can not open fastq file to save results:\n" + b, -1);
+    } else {
+      std::string a = dir + "/" + stem + ".fq" + suffix;
+      f1 = fopen(a.c_str(), "wb");
+      if (!f1) throw Error("Error: can not open fastq file to save results:\n" + a, -1);
+    }
+  }
+  void close() {
+    if (f1) fclose(f1);
+    if (f2) fclose(f2);
+    f1 = f2 = nullptr;
+  }
+  ~Sink() { close(); }
+};
+
+struct Driver {
+  Config cfg;
+  Genome genome{cfg};
+  Profile prof;
+  Engine eng;
+  simu_options opt;
+  simu_stats st{};
+  uint64_t seed = 0;
+  uint32_t batch_id = 0;
+  std::string resident;  // "popu\tchr" whose chains are on the device
+  std::vector<char> host1, host2;
+  std::vector<sg_window> wins;
+  std::vector<uint32_t> seg_size, seg_first;
+  std::vector<sg_gc_window> gcw;
+  std::vector<int32_t> gcv;
+
+  void log(const std::string& s) { if (!opt.quiet) std::cerr << s; }
+
+  void upload(const std::string& popu, const std::string& chr) {
+    const std::string key = popu + "\t" + chr;
+    if (resident == key) return;
+    ChromPlan& plan = genome.plans[popu][chr];
+    std::vector<const char*> ptr;
+    std::vector<uint64_t> len;
+    for (const std::string& c : plan.chains) { ptr.push_back(c.data()); len.push_back(c.size()); }
+    eng.check(sg_upload_haplotypes(eng.ctx, (int32_t)ptr.size(), ptr.data(), len.data()), "sg_upload_haplotypes");
+    resident = key;
+  }
+
+  // pass 1 for one chromosome: chains, windows, GC%, weights (Segment::getWeightedLength)
+  void weigh(const std::string& popu, const std::string& chr) {
+    ChromPlan& plan = genome.plans[popu][chr];
+    if (plan.windows_built) return;
+    auto t0 = Clock::now();
+    genome.build_chains(popu, chr, seed);
+    genome.build_windows(popu, chr);
+    st.t_haplotypes += since(t0);
+    t0 = Clock::now();
+    upload(popu, chr);
+    gcw.clear();
+    std::vector<uint32_t> widx;
+    for (const Segment& g : plan.segs) {
+      if (!g.has_seq || (!genome.targets.empty() && g.targets.empty())) continue;  // placeholder windows carry no GC draw
+      for (uint32_t w = g.w0; w < g.w1; w++) {
+        gcw.push_back(sg_gc_window{g.hap_base[plan.w_hap[w]] + plan.w_spos[w], plan.w_hap[w], plan.w_len[w]});
+        widx.push_back(w);
+      }
+    }
+    gcv.assign(gcw.size(), 0);
+    eng.check(sg_gc_percent(eng.ctx, gcw.data(), gcw.size(), gcv.data()), "sg_gc_percent");
+    const uint32_t ctx24 = genome.host_ctx(popu, chr);
+    const unsigned frag = Genome::kFragSize;
+    size_t q = 0;
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+      const Segment& g = plan.segs[k];
+      if (!g.has_seq || (!genome.targets.empty() && g.targets.empty())) continue;
+      for (uint32_t w = g.w0; w < g.w1; w++, q++) {
+        const double f = prof.gc_factor(gcv[q], seed, ctx24, (uint32_t)k, w - g.w0);
+        // full 1 kbp tiles: factor/fragSize; tails and targets: factor*len/(fragSize*fragSize)
+        // (Segment.cpp:576,586,615 -- the two forms round differently, keep both)
+        if (genome.targets.empty() && plan.w_len[w] == frag) plan.w_weight[w] = f / frag;
+        else plan.w_weight[w] = f * (unsigned long)plan.w_len[w] / (frag * frag);
+      }
+    }
+    st.t_plan += since(t0);
+  }
+
+  static double seg_weight(const ChromPlan& plan, const Segment& g) {
+    double s = 0;
+    for (uint32_t w = g.w0; w < g.w1; w++) s += plan.w_weight[w];
+    return s;
+  }
+
+  // Genome::setReadCounts, Genome.cpp:783-825
+  void set_read_counts(const std::string& popu, long reads) {
+    std::vector<double> chr_wl;
+    double WL = 0;
+    for (const std::string& chr : genome.chromosomes) {
+      weigh(popu, chr);
+      ChromPlan& plan = genome.plans[popu][chr];
+      double c = 0;
+      for (const Segment& g : plan.segs) c += seg_weight(plan, g);
+      WL += c;
+      chr_wl.push_back(c);
+    }
+    auto t0 = Clock::now();
+    long cur = 0;
+    for (size_t i = 0; i < genome.chromosomes.size(); i++) {
+      ChromPlan& plan = genome.plans[popu][genome.chromosomes[i]];
+      const double cw = chr_wl[i];
+      const long chr_reads = i + 1 < genome.chromosomes.size() ? (long)(reads * (cw / WL)) : reads - cur;
+      long sum = 0;
+      for (size_t j = 0; j < plan.segs.size(); j++) {
+        Segment& g = plan.segs[j];
+        if (j + 1 < plan.segs.size()) {
+          const double share = seg_weight(plan, g) / cw;
+          if (std::isnan(share)) throw Error("ERROR: chromosome " + genome.chromosomes[i] + " has zero weighted length");
+          g.read_count = (long)(share * chr_reads);
+          sum += g.read_count;
+        } else {
+          g.read_count = chr_reads - sum;
+        }
+      }
+      cur += chr_reads;
+    }
+    st.t_plan += since(t0);
+  }
+
+  // one (population, chromosome): Genome.cpp:870-887
+  void run_batch(const std::string& popu, const std::string& chr, Sink& sink) {
+    ChromPlan& plan = genome.plans[popu][chr];
+    const uint32_t bid = batch_id++;
+    if (bid > 0xFFFF) throw Error("ERROR: more than 65535 (population, chromosome) batches");
+    st.batches++;
+    const bool paired = cfg.paired();
+    auto t0 = Clock::now();
+    // windows of the segments the reference would process (Segment.cpp:675), with fragRCs
+    // (Segment::setReadCount, Segment.cpp:462-476)
+    struct Active { size_t seg; uint32_t w_first; uint64_t slots; };
+    std::vector<Active> act;
+    wins.clear(); seg_size.clear(); seg_first.clear();
+    uint64_t slot = 0;
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+      const Segment& g = plan.segs[k];
+      if (!g.has_seq || g.read_count == 0) continue;
+      const double total = seg_weight(plan, g) + 2.2204e-16;
+      const uint32_t first = (uint32_t)wins.size();
+      const uint64_t slot0 = slot;
+      long sum = 0;
+      for (uint32_t w = g.w0; w < g.w1; w++) {
+        const long rc = (long)(plan.w_weight[w] * g.read_count / total);
+        sum += rc;
+        const uint32_t h = plan.w_hap[w];
+        if (g.hap_len[h] == 0) throw Error("ERROR: sampling window on an absent haplotype (chromosome " + chr + ")");
+        wins.push_back(sg_window{g.hap_base[h], h, plan.w_spos[w], plan.w_len[w], (int32_t)rc, (uint32_t)act.size(), 0});
+      }
+      if (sum < g.read_count) wins[first].n_reads += (int32_t)(g.read_count - sum);
+      for (uint32_t i = first; i < wins.size(); i++) {
+        wins[i].slot_base = (uint32_t)slot;
+        const int n = wins[i].n_reads;
+        slot += n <= 0 ? 0 : (paired ? ((uint64_t)n + 1) / 2 : (uint64_t)n);
+      }
+      seg_size.push_back(g.seq_size() / (unsigned)g.cn);
+      seg_first.push_back(first);
+      act.push_back(Active{k, first, slot - slot0});
+    }
+    seg_first.push_back((uint32_t)wins.size());
+    if (slot > 0xFFFFFFF0ull) throw Error("ERROR: more than 2^32 fragments on chromosome " + chr);
+    st.windows += wins.size();
+    st.segments += act.size();
+    st.t_plan += since(t0);
+    if (wins.empty()) return;
+
+    // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
+    size_t a0 = 0, a1 = act.size();
+    if (opt.shard_world > 1) {
+      const uint64_t per = (slot + opt.shard_world - 1) / opt.shard_world;
+      uint64_t acc = 0;
+      a0 = a1 = act.size();
+      bool started = false;
+      for (size_t i = 0; i < act.size(); i++) {
+        const int owner = per ? (int)std::min<uint64_t>(acc / per, (uint64_t)opt.shard_world - 1) : 0;
+        if (owner == opt.shard_rank) { if (!started) { a0 = i; started = true; } a1 = i + 1; }
+        acc += act[i].slots;
+      }
+      if (!started) return;
+    }
+    const uint32_t w_lo = act[a0].w_first;
+    const uint32_t w_hi = a1 < act.size() ? act[a1].w_first : (uint32_t)wins.size();
+    const uint32_t slot_lo = wins[w_lo].slot_base;
+    std::vector<sg_window> shard(wins.begin() + w_lo, wins.begin() + w_hi);
+    std::vector<uint32_t> sh_first, sh_size;
+    for (size_t i = a0; i < a1; i++) { sh_first.push_back(act[i].w_first - w_lo); sh_size.push_back(seg_size[i]); }
+    sh_first.push_back(w_hi - w_lo);
+    for (sg_window& w : shard) { w.seg -= (uint32_t)a0; w.slot_base -= slot_lo; }
+
+    t0 = Clock::now();
+    upload(popu, chr);
+    const std::string prefix = "@" + popu + "#" + chr + "#";
+    sg_batch b;
+    std::memset(&b, 0, sizeof b);
+    b.batch_id = bid;
+    b.paired = paired ? 1 : 0;
+    b.name_prefix = prefix.c_str();
+    b.windows = shard.data();
+    b.n_windows = shard.size();
+    b.seg_size = sh_size.data();
+    b.seg_first_window = sh_first.data();
+    b.n_segs = (uint32_t)sh_size.size();
+    b.first_window = w_lo;
+    b.first_slot = slot_lo;
+    eng.check(sg_plan(eng.ctx, &b), "sg_plan");
+    uint64_t n1 = 0, n2 = 0, nf = 0;
+    const int reps = opt.repeat_sample > 1 ? opt.repeat_sample : 1;
+    for (int r = 0; r < reps; r++) {
+      eng.check(sg_sample(eng.ctx), "sg_sample");
+      eng.check(sg_result(eng.ctx, &n1, &n2, &nf), "sg_result");
+      float ms[SG_K_COUNT];
+      sg_kernel_times(eng.ctx, ms);
+      for (int i = 0; i < SG_K_COUNT; i++) st.kernel_ms[i] += ms[i];
+    }
+    st.t_sample += since(t0);
+    st.fragments += nf;
+    st.reads += paired ? 2 * nf : nf;
+    st.fastq_bytes += n1 + n2;
+    if (opt.write_files || opt.fetch) {
+      t0 = Clock::now();
+      if (host1.size() < n1) host1.resize(n1);
+      if (host2.size() < n2) host2.resize(n2);
+      eng.check(sg_fetch(eng.ctx, host1.data(), paired ? host2.data() : nullptr), "sg_fetch");
+      st.t_fetch += since(t0);
+      if (opt.write_files) {
+        t0 = Clock::now();
+        if (n1 && fwrite(host1.data(), 1, n1, sink.f1) != n1) throw Error("Error: short write to fastq file", -1);
+        if (paired && n2 && fwrite(host2.data(), 1, n2, sink.f2) != n2) throw Error("Error: short write to fastq file", -1);
+        st.t_write += since(t0);
+      }
+    }
+  }
+
+  void run(const std::string& config_path) {
+    auto t_all = Clock::now();
+    auto t0 = Clock::now();
+    cfg.load(config_path);
+    seed = opt.has_seed ? opt.seed : (uint64_t)cfg.num["seed"];
+    genome.load_data();
+    const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
+    if (opt.write_files) mkdir(out_dir.c_str(), 0755);  // src/simuReads.cpp:56-60
+    const int device = opt.device >= 0 ? opt.device : (int)cfg.num["device"];
+    if (sg_create(&eng.ctx, device, seed) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(nullptr));
+    sg_set_profiling(eng.ctx, 1);
+    prof.train(cfg.str["profile"], cfg.paired(), (int)cfg.num["insertSize"]);
+    log("profile was loaded from file " + cfg.str["profile"] + "\n");
+    sg_profile_cdf view = prof.view();
+    eng.check(sg_load_profile(eng.ctx, &view), "sg_load_profile");
+    genome.generate_segments();
+    st.t_load = since(t0);
+
+    // Genome::yieldReads
+    const std::vector<std::string>& popus = cfg.popu_names;
+    const long reads = genome.target_length() * cfg.num["coverage"] / prof.read_length;
+    st.planned_reads = (uint64_t)reads;
+    if (cfg.verbose()) log("\nNumber of reads to sample: " + std::to_string(reads) + "\n");
+    std::map<std::string, double> acn;  // Genome::calculateACNs, Genome.cpp:765-781
+    for (auto& pp : genome.plans) {
+      long sum = 0;
+      for (auto& pc : pp.second)
+        for (const Segment& g : pc.second.segs) sum += g.seq_size();
+      acn[pp.first] = (double)sum / genome.genome_length();
+    }
+    log("\n*****Generating samples*****\n");
+    const bool paired = cfg.paired();
+    const std::string suffix = opt.shard_world > 1 ? ".part" + std::to_string(opt.shard_rank) : "";
+    Sink sink;
+    if (genome.mix_props.empty()) {
+      if (opt.write_files) sink.open(out_dir, popus[0], paired, suffix);
+      set_read_counts(popus[0], reads);
+      for (const std::string& chr : genome.chromosomes) run_batch(popus[0], chr, sink);
+    } else {
+      for (const std::vector<float>& props : genome.mix_props) {
+        double w_acn = 0;
+        std::string stem;
+        char buf[1000];
+        for (size_t i = 0; i < popus.size(); i++) {
+          w_acn += props[i] * acn[popus[i]];
+          snprintf(buf, sizeof buf, i == 0 ? "%s_%.3f" : "+%s_%.3f", popus[i].c_str(), props[i]);
+          stem += buf;
+        }
+        if (opt.write_files) sink.open(out_dir, stem, paired, suffix);
+        for (size_t i = 0; i < popus.size(); i++) {
+          const long popu_reads = (long)(reads * props[i] * acn[popus[i]] / w_acn);  // long*float is a float product (Genome.cpp:935)
+          set_read_counts(popus[i], popu_reads);
+          for (const std::string& chr : genome.chromosomes) run_batch(popus[i], chr, sink);
+        }
+      }
+    }
+    sink.close();
+    log("\nReads generation done!\n");
+    st.t_total = since(t_all);
+  }
+};
+
+}  // namespace
+}  // namespace simu
+
+extern "C" void simu_default_options(simu_options* o) {
+  std::memset(o, 0, sizeof *o);
+  o->device = -1;
+  o->write_files = 1;
+  o->shard_world = 1;
+}
+
+extern "C" int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats, char* err, size_t err_len) {
+  simu_options o;
+  if (opt) o = *opt; else simu_default_options(&o);
+  if (o.shard_world < 1) o.shard_world = 1;
+  auto set_err = [&](const std::string& m) {
+    if (err && err_len) { strncpy(err, m.c_str(), err_len - 1); err[err_len - 1] = '\0'; }
+  };
+  try {
+    std::unique_ptr<simu::Driver> d(new simu::Driver());
+    d->opt = o;
+    d->run(config_path ? config_path : "");
+    if (stats) *stats = d->st;
+    return 0;
+  } catch (const simu::Error& e) {
+    set_err(e.what());
+    return e.exit_code == 0 ? 1 : e.exit_code;
+  } catch (const std::exception& e) {
+    set_err(e.what());
+    return 1;
+  }
+}

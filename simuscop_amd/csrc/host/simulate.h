@@ -1,0 +1,47 @@
+// host/simulate.h -- `simuReads <config>` as a library call (used by the CLI, tests and bench.py).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct simu_options {
+  int32_t device;          // -1: take `device` from the config (default 0)
+  int32_t has_seed;        // 0: take `seed` from the config
+  uint64_t seed;
+  int32_t write_files;     // 1: write FASTQ like the reference (SeqWriter); 0: keep results on the device only
+  int32_t fetch;           // with write_files == 0: still copy the FASTQ text to (pinned) host memory
+  int32_t quiet;           // suppress the reference's stderr progress lines
+  int32_t shard_rank;      // multi-GPU: this process samples batches with (batch ordinal % shard_world) == shard_rank
+  int32_t shard_world;     // 1 = no sharding
+  const char* output_dir;  // NULL / "": use the config's `output`
+  int32_t repeat_sample;   // >1: re-run sg_sample this many times per batch (kernel timing experiments)
+} simu_options;
+
+typedef struct simu_stats {
+  uint64_t reads;          // FASTQ records produced (both mates counted)
+  uint64_t fragments;      // pairs (PE) or reads (SE)
+  uint64_t fastq_bytes;
+  uint64_t planned_reads;  // Genome::yieldReads `reads` (Genome.cpp:831)
+  uint64_t windows, segments, batches;
+  double t_load;           // config + inputs + profile
+  double t_haplotypes;     // build chains (host)
+  double t_plan;           // GC scan (device) + weights + read counts (host)
+  double t_sample;         // sg_plan + sg_sample + sg_result (GPU pass, wall)
+  double t_fetch;          // D2H of FASTQ text
+  double t_write;          // file output
+  double t_total;
+  float kernel_ms[8];      // summed per kernel (SG_K_*)
+} simu_stats;
+
+// Returns 0 on success.  On failure returns the exit code the reference would use and writes the
+// message it would print to `err`.
+int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats, char* err, size_t err_len);
+
+void simu_default_options(simu_options* opt);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,490 @@
+// sg_api.cpp -- C ABI (include/simuscop_amd.h) on top of the gfx950 kernels.
+//
+// Everything here is host plumbing: table conversion, grow-only device buffers (sized for a
+// 288 GB HBM3E part: a whole chromosome's haplotypes, plan and FASTQ text stay resident), kernel
+// sequencing on one HIP stream.  There is no CPU fallback: without a HIP device sg_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sg_device.h"
+#include "sg_tables.h"
+
+namespace sg {
+void launch_plan(const DevProfile& P, const DevBatch& B, hipStream_t s);
+void launch_namebase(const DevBatch& B, hipStream_t s);
+void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
+uint32_t scan_blocks(uint32_t n);
+void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s);
+void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
+}  // namespace sg
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return (int)e; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct sg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  uint64_t seed = 0;
+  std::string err;
+
+  bool have_profile = false, have_haps = false, have_plan = false, sampled = false;
+  sg::DevProfile P{};
+  sg::DevBatch B{};
+  DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
+      recoff, totals, bsum, out1, out2, gcw, gco;
+  uint64_t host_totals[4] = {0, 0, 0, 0};
+  bool results_valid = false;
+
+  bool profiling = false;
+  hipEvent_t evs[SG_K_COUNT + 1] = {};
+  bool evs_created = false;
+  float last_ms[SG_K_COUNT] = {0, 0, 0, 0, 0};
+
+  int fail(int code, const std::string& m) { err = m; return code; }
+  int hipfail(hipError_t e, const char* what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return SG_ERR_HIP;
+  }
+};
+
+#define SG_HIP(call)                                        \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return ctx->hipfail(_e, #call);   \
+  } while (0)
+#define SG_ENSURE(buf, bytes)                                                                  \
+  do {                                                                                         \
+    int _e = (buf).ensure(bytes);                                                              \
+    if (_e) return ctx->hipfail((hipError_t)_e, "hipMalloc(" #buf ")");                        \
+  } while (0)
+
+extern "C" {
+
+uint64_t sg_cdf_count_le(double c) { return sg::count_le(c); }
+
+const char* sg_last_error(const sg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sg_create(sg_ctx** out, int device, uint64_t seed) {
+  if (!out) { g_create_error = "sg_create: null output pointer"; return SG_ERR_INVALID; }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("sg_create: no HIP device available (") + hipGetErrorString(e) +
+                     "); this engine has no CPU path";
+    return SG_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) { g_create_error = "sg_create: device index out of range"; return SG_ERR_INVALID; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return SG_ERR_HIP; }
+  sg_ctx* ctx = new sg_ctx();
+  ctx->device = device;
+  ctx->seed = seed;
+  e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return SG_ERR_HIP; }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return SG_OK;
+}
+
+void sg_destroy(sg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
+                    &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
+                    &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco})
+    b->release();
+  if (ctx->evs_created)
+    for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int sg_set_stream(sg_ctx* ctx, void* hip_stream) {
+  if (!ctx) return SG_ERR_INVALID;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return SG_OK;
+}
+
+int sg_set_seed(sg_ctx* ctx, uint64_t seed) {
+  if (!ctx) return SG_ERR_INVALID;
+  ctx->seed = seed;
+  return SG_OK;
+}
+
+int sg_set_profiling(sg_ctx* ctx, int enable) {
+  if (!ctx) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  if (enable && !ctx->evs_created) {
+    for (auto& ev : ctx->evs) SG_HIP(hipEventCreate(&ev));
+    ctx->evs_created = true;
+  }
+  ctx->profiling = enable != 0;
+  return SG_OK;
+}
+
+int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]) {
+  if (!ctx || !ms) return SG_ERR_INVALID;
+  for (int i = 0; i < SG_K_COUNT; i++) ms[i] = ctx->last_ms[i];
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
+  if (!ctx || !pr) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  if (pr->n_bases != 4) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: only 4-letter base alphabets are supported");
+  if (pr->kmer < 1 || pr->kmer > 6) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: kmer must be in 1..6");
+  if (pr->bins < 1 || pr->read_length < 1 || pr->read_length > 30000) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad bins/read_length");
+  if (pr->n_qual < 1 || pr->n_qual > 4096) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad n_qual");
+  if (!pr->subs_cdf1 || !pr->qual_cdf || !pr->ins_cdf || !pr->del_cdf || pr->n_ins < 1 || pr->n_del < 1)
+    return ctx->fail(SG_ERR_INVALID, "sg_load_profile: missing table");
+  // base alphabet must be a permutation of ACGT (the kernels classify haplotype bytes by value)
+  uint32_t remap = 0, packed = 0;
+  {
+    const char nat[4] = {'A', 'C', 'T', 'G'};  // natural index = (byte >> 1) & 3
+    for (int n = 0; n < 4; n++) {
+      int code = -1;
+      for (int k = 0; k < 4; k++) if (pr->bases[k] == nat[n]) code = k;
+      if (code < 0) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: bases must be a permutation of ACGT");
+      remap |= (uint32_t)code << (2 * n);
+    }
+    for (int k = 0; k < 4; k++) packed |= (uint32_t)(uint8_t)pr->bases[k] << (8 * k);
+  }
+  int kmer_count = 0;
+  {
+    int p = 1;
+    for (int m = 1; m <= pr->kmer; m++) { p *= 4; kmer_count += p; }
+  }
+  const int bins = pr->bins;
+  const bool has2 = pr->subs_cdf2 != nullptr;
+
+  std::vector<uint32_t> tab;
+  // substitution rows
+  const size_t sub_rows = (size_t)kmer_count * bins;
+  const size_t sub_off = 0;
+  tab.resize((has2 ? 2 : 1) * sub_rows * 4);
+  for (int t = 0; t < (has2 ? 2 : 1); t++) {
+    const double* src = t == 0 ? pr->subs_cdf1 : pr->subs_cdf2;
+    for (size_t r = 0; r < sub_rows; r++) sg::encode_sub_row(src + r * 4, &tab[(t * sub_rows + r) * 4]);
+  }
+  // quality rows
+  const size_t qrows = (size_t)16 * bins;
+  std::vector<sg::Row> qr(qrows);
+  uint32_t wmax = 1;
+  for (size_t r = 0; r < qrows; r++) {
+    qr[r] = sg::encode_row(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
+    if (qr[r].T.size() > wmax) wmax = (uint32_t)qr[r].T.size();
+  }
+  const uint32_t qW = sg::pow2_at_least(wmax), qstride = qW + 1;
+  const size_t qual_off = tab.size();
+  tab.resize(qual_off + qrows * qstride, 0xFFFFFFFFu);
+  for (size_t r = 0; r < qrows; r++) {
+    uint32_t* row = &tab[qual_off + r * qstride];
+    row[0] = qr[r].k0;
+    for (size_t i = 0; i < qr[r].T.size(); i++) row[1 + i] = qr[r].T[i];
+  }
+  auto add_row = [&](const double* cdf, int n, size_t& off, uint32_t& lg) {
+    sg::Row r = sg::encode_row(cdf, n);
+    uint32_t W = sg::pow2_at_least((uint32_t)r.T.size());
+    lg = sg::log2u(W);
+    off = tab.size();
+    tab.resize(off + 1 + W, 0xFFFFFFFFu);
+    tab[off] = r.k0;
+    for (size_t i = 0; i < r.T.size(); i++) tab[off + 1 + i] = r.T[i];
+    while (tab.size() % 4) tab.push_back(0xFFFFFFFFu);
+  };
+  size_t ins_off, del_off, isz_off = 0;
+  uint32_t ins_lg, del_lg, isz_lg = 0;
+  while (tab.size() % 4) tab.push_back(0xFFFFFFFFu);
+  add_row(pr->ins_cdf, pr->n_ins, ins_off, ins_lg);
+  add_row(pr->del_cdf, pr->n_del, del_off, del_lg);
+  const bool has_isz = pr->isize_cdf != nullptr && pr->n_isize > 0;
+  if (has_isz) add_row(pr->isize_cdf, pr->n_isize, isz_off, isz_lg);
+
+  SG_ENSURE(ctx->tab, tab.size() * 4);
+  SG_HIP(hipMemcpyAsync(ctx->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+
+  sg::DevProfile& P = ctx->P;
+  const uint32_t* base = ctx->tab.as<uint32_t>();
+  P.sub = (const uint4*)(base + sub_off);
+  P.sub_mate_rows = has2 ? (uint32_t)sub_rows : 0u;
+  P.qual = base + qual_off;
+  P.qual_stride = qstride;
+  P.qual_lg = sg::log2u(qW);
+  P.ins_row = base + ins_off; P.ins_lg = ins_lg;
+  P.del_row = base + del_off; P.del_lg = del_lg;
+  P.isz_row = has_isz ? base + isz_off : nullptr; P.isz_lg = isz_lg;
+  P.isz_min = pr->isize_min;
+  P.fixed_isz = pr->insert_size;
+  // getIndelSeq: `p <= insertRate`, then `p < delRate/(1-insertRate)` with p = x/2^32 (Profile.cpp:1560-1570)
+  uint64_t ci = sg::count_unit_le(pr->insert_rate);
+  P.Tins = (uint32_t)(ci - 1);  // ci >= 1 for any rate >= 0
+  if (pr->insert_rate < 0) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: negative insert rate");
+  double d = pr->del_rate / (1 - pr->insert_rate);
+  uint64_t cd = sg::count_unit_lt(d);
+  if (cd > 0xFFFFFFFFull) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: deletion rate >= 1");
+  P.Cdel = (uint32_t)cd;
+  P.L = pr->read_length; P.bins = bins; P.kmer = pr->kmer; P.min_qual = pr->min_qual;
+  P.remap_packed = remap; P.bases_packed = packed;
+  {
+    uint32_t off = 0, p = 1;
+    for (int m = 0; m < 8; m++) P.kmer_off[m] = 0;
+    for (int m = 1; m <= pr->kmer; m++) { P.kmer_off[m] = off; p *= 4; off += p; }
+  }
+  ctx->have_profile = true;
+  ctx->have_plan = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chains, const uint64_t* lens) {
+  if (!ctx || n_chains < 0 || (n_chains && (!chains || !lens))) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  const size_t PAD = 64;
+  std::vector<uint64_t> meta(2 * (size_t)n_chains + 2, 0);  // [off..., len...]
+  size_t total = 0;
+  for (int c = 0; c < n_chains; c++) {
+    meta[c] = total;
+    meta[n_chains + c] = lens[c];
+    total += (lens[c] + PAD + 63) & ~(size_t)63;
+  }
+  total += PAD;
+  SG_ENSURE(ctx->chains, total);
+  SG_ENSURE(ctx->chain_meta, meta.size() * 8);
+  SG_HIP(hipMemsetAsync(ctx->chains.p, 'N', total, ctx->stream));
+  for (int c = 0; c < n_chains; c++)
+    if (lens[c]) SG_HIP(hipMemcpyAsync((uint8_t*)ctx->chains.p + meta[c], chains[c], lens[c], hipMemcpyHostToDevice, ctx->stream));
+  SG_HIP(hipMemcpyAsync(ctx->chain_meta.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->B.chains = ctx->chains.as<uint8_t>();
+  ctx->B.chain_off = ctx->chain_meta.as<uint64_t>();
+  ctx->B.chain_len = ctx->chain_meta.as<uint64_t>() + n_chains;
+  ctx->have_haps = true;
+  ctx->have_plan = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int sg_plan(sg_ctx* ctx, const sg_batch* b) {
+  if (!ctx || !b) return SG_ERR_INVALID;
+  if (!ctx->have_profile) return ctx->fail(SG_ERR_INVALID, "sg_plan: call sg_load_profile first");
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_plan: call sg_upload_haplotypes first");
+  if (b->n_windows && (!b->windows || !b->seg_size || !b->seg_first_window)) return ctx->fail(SG_ERR_INVALID, "sg_plan: null arrays");
+  if (b->n_windows > 0xFFFFFFFFull) return ctx->fail(SG_ERR_INVALID, "sg_plan: more than 2^32 windows in one batch");
+  if (b->batch_id > 0xFFFF) return ctx->fail(SG_ERR_INVALID, "sg_plan: batch_id must fit 16 bits");
+  SG_HIP(hipSetDevice(ctx->device));
+  // validate the plan on the host: every operand shape the kernels assume
+  uint64_t slots = 0;
+  const uint64_t nw = b->n_windows;
+  for (uint64_t w = 0; w < nw; w++) {
+    const sg_window& x = b->windows[w];
+    if (x.seg >= b->n_segs) return ctx->fail(SG_ERR_INVALID, "sg_plan: window.seg out of range");
+    if (x.slot_base != slots) return ctx->fail(SG_ERR_INVALID, "sg_plan: window.slot_base is not the running prefix sum");
+    if (x.len == 0) return ctx->fail(SG_ERR_INVALID, "sg_plan: empty window");
+    if (b->seg_size[x.seg] == 0) return ctx->fail(SG_ERR_INVALID, "sg_plan: seg_size 0");
+    uint64_t planned = x.n_reads <= 0 ? 0 : (b->paired ? ((uint64_t)x.n_reads + 1) / 2 : (uint64_t)x.n_reads);
+    slots += planned;
+    if (slots > 0xFFFFFFF0ull) return ctx->fail(SG_ERR_INVALID, "sg_plan: more than 2^32 fragments in one batch");
+  }
+  for (uint32_t s = 0; s < b->n_segs; s++)
+    if (b->seg_first_window[s] > b->seg_first_window[s + 1] || b->seg_first_window[s + 1] > nw)
+      return ctx->fail(SG_ERR_INVALID, "sg_plan: seg_first_window not monotone");
+  if (b->n_segs && (b->seg_first_window[0] != 0 || b->seg_first_window[b->n_segs] != nw))
+    return ctx->fail(SG_ERR_INVALID, "sg_plan: seg_first_window must cover all windows");
+  const size_t plen = b->name_prefix ? strlen(b->name_prefix) : 0;
+  if (plen == 0 || plen > 4096) return ctx->fail(SG_ERR_INVALID, "sg_plan: bad name_prefix");
+  // chain bounds need the chain lengths: read them back once (tiny)
+  {
+    const size_t nch = (size_t)(ctx->B.chain_len - ctx->B.chain_off);
+    std::vector<uint64_t> meta(2 * nch);
+    if (nch) SG_HIP(hipMemcpy(meta.data(), ctx->chain_meta.p, meta.size() * 8, hipMemcpyDeviceToHost));
+    for (uint64_t w = 0; w < nw; w++) {
+      const sg_window& x = b->windows[w];
+      if (x.chain >= nch) return ctx->fail(SG_ERR_INVALID, "sg_plan: window.chain out of range");
+      if (x.hap_base + x.spos + x.len > meta[nch + x.chain]) return ctx->fail(SG_ERR_INVALID, "sg_plan: window runs past its chain");
+    }
+  }
+  const uint32_t n_slots = (uint32_t)slots;
+  const uint32_t nm = b->paired ? 2 : 1;
+
+  SG_ENSURE(ctx->windows, (nw + 1) * sizeof(sg_window));
+  SG_ENSURE(ctx->segmeta, ((size_t)b->n_segs * 2 + 2) * 4);
+  SG_ENSURE(ctx->prefix, plen + 16);
+  SG_ENSURE(ctx->pairs, ((size_t)n_slots + 1) * sizeof(sg::PairRec));
+  SG_ENSURE(ctx->win_actual, (nw + 1) * 4);
+  SG_ENSURE(ctx->win_namebase, (nw + 1) * 4);
+  SG_ENSURE(ctx->rlen, ((size_t)nm * n_slots + 1) * 4);
+  SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
+  SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
+  SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
+  SG_ENSURE(ctx->totals, 4 * 8);
+  SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
+
+  if (nw) SG_HIP(hipMemcpyAsync(ctx->windows.p, b->windows, nw * sizeof(sg_window), hipMemcpyHostToDevice, ctx->stream));
+  if (b->n_segs) {
+    SG_HIP(hipMemcpyAsync(ctx->segmeta.p, b->seg_size, (size_t)b->n_segs * 4, hipMemcpyHostToDevice, ctx->stream));
+    SG_HIP(hipMemcpyAsync(ctx->segmeta.as<uint32_t>() + b->n_segs, b->seg_first_window, ((size_t)b->n_segs + 1) * 4,
+                          hipMemcpyHostToDevice, ctx->stream));
+  }
+  SG_HIP(hipMemcpyAsync(ctx->prefix.p, b->name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+
+  sg::DevBatch& B = ctx->B;
+  B.windows = ctx->windows.as<sg_window>();
+  B.n_windows = nw;
+  B.seg_size = ctx->segmeta.as<uint32_t>();
+  B.seg_first_window = ctx->segmeta.as<uint32_t>() + b->n_segs;
+  B.n_segs = b->n_segs;
+  B.n_slots = n_slots;
+  B.batch_id = b->batch_id;
+  B.win_offset = b->first_window;
+  B.slot_offset = b->first_slot;
+  B.paired = b->paired ? 1 : 0;
+  B.prefix = ctx->prefix.as<uint8_t>();
+  B.prefix_len = (uint32_t)plen;
+  B.pairs = ctx->pairs.as<sg::PairRec>();
+  B.win_actual = ctx->win_actual.as<uint32_t>();
+  B.win_namebase = ctx->win_namebase.as<uint32_t>();
+  B.rlen = ctx->rlen.as<uint32_t>();
+  B.events = ctx->events.as<uint32_t>();
+  B.reclen = ctx->reclen.as<uint32_t>();
+  B.recoff = ctx->recoff.as<uint64_t>();
+  B.totals = ctx->totals.as<uint64_t>();
+  ctx->have_plan = true;
+  ctx->sampled = false;
+  ctx->results_valid = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int run_pass(sg_ctx* ctx) {
+  sg::DevBatch& B = ctx->B;
+  B.k0 = (uint32_t)ctx->seed;
+  B.k1 = (uint32_t)(ctx->seed >> 32);
+  hipStream_t s = ctx->stream;
+  const bool prof = ctx->profiling;
+  SG_HIP(hipMemsetAsync(B.totals, 0, 4 * 8, s));
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
+  sg::launch_plan(ctx->P, B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));
+  sg::launch_namebase(B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[2], s));
+  sg::launch_indel(ctx->P, B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[3], s));
+  sg::launch_scan(B, ctx->bsum.as<uint64_t>(), s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[4], s));
+  SG_HIP(hipGetLastError());
+  // The FASTQ size is only known now.  Reading two u64 back costs one stream sync per batch
+  // (a batch is a whole chromosome); the output buffers then grow if needed.
+  SG_HIP(hipMemcpyAsync(ctx->host_totals, B.totals, 4 * 8, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  if (ctx->host_totals[3] & 1) return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
+  SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
+  if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
+  B.out[0] = ctx->out1.as<uint8_t>();
+  B.out[1] = ctx->out2.as<uint8_t>();
+  B.out_cap[0] = ctx->out1.cap;
+  B.out_cap[1] = ctx->out2.cap;
+  sg::launch_emit(ctx->P, B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));
+  SG_HIP(hipGetLastError());
+  ctx->sampled = true;
+  ctx->results_valid = false;
+  return SG_OK;
+}
+
+int sg_sample(sg_ctx* ctx) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->have_plan) return ctx->fail(SG_ERR_INVALID, "sg_sample: call sg_plan first");
+  SG_HIP(hipSetDevice(ctx->device));
+  return run_pass(ctx);
+}
+
+int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_fragments) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_result: call sg_sample first");
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->profiling) {
+    for (int i = 0; i < SG_K_COUNT; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
+  }
+  ctx->results_valid = true;
+  if (bytes_r1) *bytes_r1 = ctx->host_totals[0];
+  if (bytes_r2) *bytes_r2 = ctx->B.paired ? ctx->host_totals[1] : 0;
+  if (n_fragments) *n_fragments = ctx->host_totals[2];
+  return SG_OK;
+}
+
+int sg_fetch(sg_ctx* ctx, char* host_r1, char* host_r2) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_fetch: call sg_sample first");
+  SG_HIP(hipSetDevice(ctx->device));
+  if (host_r1 && ctx->host_totals[0])
+    SG_HIP(hipMemcpyAsync(host_r1, ctx->out1.p, ctx->host_totals[0], hipMemcpyDeviceToHost, ctx->stream));
+  if (host_r2 && ctx->B.paired && ctx->host_totals[1])
+    SG_HIP(hipMemcpyAsync(host_r2, ctx->out2.p, ctx->host_totals[1], hipMemcpyDeviceToHost, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  return SG_OK;
+}
+
+int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_device_output: call sg_sample first");
+  if (dev_r1) *dev_r1 = ctx->out1.p;
+  if (dev_r2) *dev_r2 = ctx->B.paired ? ctx->out2.p : nullptr;
+  return SG_OK;
+}
+
+int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t* gc_out) {
+  if (!ctx || (n && (!windows || !gc_out))) return SG_ERR_INVALID;
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_gc_percent: call sg_upload_haplotypes first");
+  if (!n) return SG_OK;
+  SG_HIP(hipSetDevice(ctx->device));
+  {
+    const size_t nch = (size_t)(ctx->B.chain_len - ctx->B.chain_off);
+    std::vector<uint64_t> meta(2 * nch);
+    if (nch) SG_HIP(hipMemcpy(meta.data(), ctx->chain_meta.p, meta.size() * 8, hipMemcpyDeviceToHost));
+    for (uint64_t w = 0; w < n; w++) {
+      if (windows[w].chain >= nch) return ctx->fail(SG_ERR_INVALID, "sg_gc_percent: chain out of range");
+      if (windows[w].start + windows[w].len > meta[nch + windows[w].chain]) return ctx->fail(SG_ERR_INVALID, "sg_gc_percent: window runs past its chain");
+    }
+  }
+  SG_ENSURE(ctx->gcw, n * sizeof(sg_gc_window));
+  SG_ENSURE(ctx->gco, n * 4);
+  SG_HIP(hipMemcpyAsync(ctx->gcw.p, windows, n * sizeof(sg_gc_window), hipMemcpyHostToDevice, ctx->stream));
+  sg::launch_gc(ctx->B.chains, ctx->B.chain_off, ctx->gcw.as<sg_gc_window>(), n, ctx->gco.as<int32_t>(), ctx->stream);
+  SG_HIP(hipGetLastError());
+  SG_HIP(hipMemcpyAsync(gc_out, ctx->gco.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  return SG_OK;
+}
+
+}  // extern "C"

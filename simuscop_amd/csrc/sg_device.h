@@ -1,0 +1,70 @@
+// sg_device.h -- device-side data layout shared by the kernels and the host API (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/simuscop_amd.h"
+
+namespace sg {
+
+// RNG stream kinds (DESIGN.md "RNG addressing"); c3 = kind | (ctx24 << 8)
+enum : uint32_t { KIND_HAP = 1, KIND_GC = 2, KIND_PLAN = 3, KIND_INDEL = 4, KIND_AUX = 5, KIND_BASE = 6 };
+
+// One planned fragment (16 B).  Written by plan_kernel, read by the indel and emit kernels.
+struct PairRec {
+  uint32_t win;     // window index in the batch
+  uint32_t relpos;  // pos - window.spos
+  uint32_t fl;      // bits 0..30 fragment length after chain-end clipping (0 = slot unused), bit 31 = SE reverse strand
+  uint32_t k;       // ordinal of the fragment inside its window
+};
+
+// Sequencing-indel event (Profile::getIndelSeq outcome): j | len<<16 | del<<31
+__host__ __device__ inline uint32_t ev_pack(uint32_t j, uint32_t len, uint32_t del) { return j | (len << 16) | (del << 31); }
+
+struct DevProfile {
+  const uint4* sub;            // [mate][kmer_count][bins] rows {T0,T1,T2,k0}
+  uint32_t sub_mate_rows;      // rows per mate table (0 when mate 2 shares mate 1's table)
+  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {k0, T0..T(W-1)}
+  uint32_t qual_stride, qual_lg;
+  const uint32_t* ins_row; uint32_t ins_lg;
+  const uint32_t* del_row; uint32_t del_lg;
+  const uint32_t* isz_row; uint32_t isz_lg;  // isz_row == nullptr -> fixed insert size
+  int32_t isz_min, fixed_isz;
+  uint32_t Tins;               // insertion iff x <= Tins
+  uint32_t Cdel;               // deletion  iff x <  Cdel
+  int32_t L, bins, kmer, min_qual;
+  uint32_t remap_packed;       // natural index (A0 C1 T2 G3) -> profile base code, 2 bits each
+  uint32_t bases_packed;       // profile base code -> ASCII, 8 bits each
+  uint32_t kmer_off[8];        // kmer_off[m] = first table index of contexts with m real bases
+};
+
+struct DevBatch {
+  const uint8_t* chains;        // all chains, each padded; chain c starts at chain_off[c]
+  const uint64_t* chain_off;
+  const uint64_t* chain_len;
+  const sg_window* windows;
+  uint64_t n_windows;
+  const uint32_t* seg_size;
+  const uint32_t* seg_first_window;
+  uint32_t n_segs;
+  uint32_t n_slots;             // planned fragments in the batch
+  uint32_t batch_id;
+  uint32_t win_offset, slot_offset;  // philox address of local window 0 / local slot 0 (sharded batches)
+  int32_t paired;
+  const uint8_t* prefix;        // "@popu#chr#"
+  uint32_t prefix_len;
+  uint32_t k0, k1;              // philox key
+  // work buffers
+  PairRec* pairs;               // [n_slots]
+  uint32_t* win_actual;         // [n_windows] fragments actually produced per window
+  uint32_t* win_namebase;       // [n_windows] fragments produced by earlier windows of the same segment
+  uint32_t* rlen;               // [2][n_slots]  n' | nev<<16
+  uint32_t* events;             // [2][n_slots][SG_MAX_EVENTS]
+  uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
+  uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
+  uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] error flags
+  uint8_t* out[2];
+  uint64_t out_cap[2];
+};
+
+}  // namespace sg
