@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated paired reads/sec of the MI355X read-sampling pass.
+
+Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C2"): one synthetic contig of GRCh38 chr20 length
+(64,444,167 bp), HiSeqXTen profile (151 bp), PE, 30x, insertSize 350 -> ~6.4 M pairs per step.
+A step = one full sampling pass over that chromosome (plan draws, indel pass, offset scan, per-base
+substitution/quality sampling, FASTQ formatting) with haplotypes, tables and plan already resident in
+HBM; FASTQ text stays in HBM (PCIe/file rates are reported separately in DESIGN.md).
+
+Multi-GPU (torchrun, one rank per GPU): weak scaling -- every rank owns one chr20-sized chromosome
+of an N-chromosome genome.  The only exchange is the read-count balancing step of
+Genome::setReadCounts (Genome.cpp:783-825): an all_gather of the per-chromosome GC-weighted lengths
+over RCCL, after which every rank derives its read count exactly as the reference apportions
+`reads*chrWL/WL`.  No data-path collective.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHR20_LEN = 64444167
+TESTDATA = os.path.join(ROOT, "tests", "golden", "testData")
+BYTES_PER_PAIR_FMT = "2*L haplotype bytes read + 2 FASTQ records written"
+
+
+def write_config(path, fasta, out_dir, coverage=30, threads=1, profile="Illumina_HiSeqXTen.profile"):
+    with open(path, "w") as f:
+        f.write(f"ref = {fasta}\nprofile = {os.path.join(TESTDATA, profile)}\nname = sim\noutput = {out_dir}\n"
+                f"layout = PE\nthreads = {threads}\nverbose = 0\ncoverage = {coverage}\ninsertSize = 350\n")
+
+
+def cpu_baseline(workdir, cores):
+    """Time the reference's CPU thread-pool path on a bounded sample of the same workload.
+
+    Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
+    Fallback (binary absent): the oracle restatement (kind "port").  Sample: a 16 Mbp contig of the
+    same synthetic genome at 30x (one <=1 Mbp segment per worker thread, Genome.cpp:876-883)."""
+    from simuscop_amd import synth
+    sample_len = 16_000_000
+    fa = os.path.join(workdir, "cpu_sample.fa")
+    synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
+    cfg = os.path.join(workdir, "cpu_config.txt")
+    out = os.path.join(workdir, "cpu_out")
+    write_config(cfg, fa, out, threads=cores)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "simuReads")
+    kind = "reference"
+    if os.path.exists(ref_bin):
+        cmd = [ref_bin, cfg]
+    else:
+        kind = "port"
+        cmd = [os.path.join(ROOT, "oracle", "oracle_cli"), cfg, "--rng", "philox", "--threads", str(cores)]
+    t0 = time.time()
+    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dt = time.time() - t0
+    if r.returncode != 0:
+        return None
+    lines = 0
+    with open(os.path.join(out, "sim_1.fq"), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            lines += blk.count(b"\n")
+    pairs = lines // 4
+    for fn in os.listdir(out):
+        os.remove(os.path.join(out, fn))
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": f"{sample_len} bp contig, XTen PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
+                      f"(whole run incl. input load, threads={cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import simuscop_amd
+    from simuscop_amd import synth
+
+    workdir = tempfile.mkdtemp(prefix=f"simuscop_bench_r{rank}_")
+    fasta = os.path.join(workdir, "ref.fa")
+    # rank r owns chromosome r of an N-chromosome synthetic genome (contig index = rank)
+    seq = synth.synth_contig(args.contig_len, seed=20, contig_index=rank)
+    with open(fasta, "wb") as f:
+        f.write(b">chr20\n")
+        full = (args.contig_len // 60) * 60
+        import numpy as np
+        body = np.empty((full // 60, 61), dtype=np.uint8)
+        body[:, :60] = seq[:full].reshape(-1, 60)
+        body[:, 60] = 10
+        f.write(body.tobytes())
+        if full < args.contig_len:
+            f.write(seq[full:].tobytes() + b"\n")
+    del seq
+    cfg = os.path.join(workdir, "config.txt")
+    write_config(cfg, fasta, os.path.join(workdir, "out"), coverage=args.coverage)
+
+    sess = simuscop_amd.Session(cfg, device=local_rank, write_files=0, quiet=1, seed=0x5EED0000 + rank)
+    L = 151
+    # ---- read-count balancing (Genome::setReadCounts) ----
+    my_wl = sess.weighted_length()
+    my_target = args.contig_len
+    if world > 1:
+        t = torch.tensor([my_wl, float(my_target)], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)           # RCCL over xGMI: 16 bytes per rank
+        wls = [float(v[0]) for v in allv]
+        total_len = int(sum(float(v[1]) for v in allv))
+    else:
+        wls, total_len = [my_wl], my_target
+    reads = total_len * args.coverage // L           # Genome.cpp:831
+    WL = 0.0
+    for w in wls:
+        WL += w
+    cur, my_reads = 0, 0
+    for i, w in enumerate(wls):                      # Genome.cpp:806-811
+        chr_reads = int(reads * (w / WL)) if i < len(wls) - 1 else reads - cur
+        if i == rank:
+            my_reads = chr_reads
+        cur += chr_reads
+    sess.set_reads(my_reads)
+    assert sess.prepare_batch(0)
+    stream = torch.cuda.current_stream()
+    sess.set_stream(stream.cuda_stream)
+
+    def step():
+        sess.sample()
+        return sess.result()   # waits for the pass (stream sync) and returns sizes
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pairs = 0
+    kms = {k: 0.0 for k in simuscop_amd.SG_K_NAMES}
+    fq_bytes = 0
+    for _ in range(args.steps):
+        b1, b2, nf = step()
+        pairs += nf
+        fq_bytes = b1 + b2
+        for k, v in sess.kernel_times().items():   # HIP events recorded on this stream inside the engine
+            kms[k] += v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, total_pairs = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, total_pairs = dt, float(pairs)
+
+    if rank == 0:
+        pairs_per_step = pairs / args.steps
+        emit_ms = kms["emit"] / args.steps
+        bytes_per_pair = 2 * L + fq_bytes / max(pairs_per_step, 1)   # measured FASTQ bytes/pair + 2L reference bytes
+        achieved = pairs_per_step * bytes_per_pair / (emit_ms * 1e-3) / 1e9
+        out = {
+            "metric": "simulated paired reads/sec (whole node) at 30x WGS PE150",
+            "value": total_pairs / dt_max,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU (GRCh38 chr20 length), HiSeqXTen profile "
+                                   f"(151 bp), PE, {args.coverage}x, insertSize 350",
+                       "pairs_per_step_per_gpu": pairs_per_step, "parallelism": f"{world} x 1 chromosome shard"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "emit_kernel", "kernel_ms": emit_ms,
+                         "algorithmic_bytes_per_pair": bytes_per_pair, "bytes_note": BYTES_PER_PAIR_FMT},
+            "kernel_ms_per_step": {k: v / args.steps for k, v in kms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = min(16, os.cpu_count() or 1)
+            try:
+                out["cpu_baseline"] = cpu_baseline(workdir, cores)
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = None
+                out["cpu_baseline_error"] = repr(e)
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    import shutil
+    shutil.rmtree(workdir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,248 @@
+"""simuscop_amd -- MI355X-native read-sampling engine behind SimuSCoP's simuReads surface.
+
+Python is only glue here (ctypes over the C ABI in include/simuscop_amd.h and over the C++ host
+library); the product is `lib/libsimuscop_amd.so` (HIP kernels, gfx950), `lib/libsimuscop_host.so`
+and the `lib/simuReads` command line.  There is no Python or CPU compute path: loading fails loudly
+when the native libraries are missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+ENGINE_SO = os.path.join(LIB_DIR, "libsimuscop_amd.so")
+HOST_SO = os.path.join(LIB_DIR, "libsimuscop_host.so")
+SIMUREADS = os.path.join(LIB_DIR, "simuReads")
+
+SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit"]
+
+# every symbol include/simuscop_amd.h declares
+ENGINE_SYMBOLS = [
+    "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
+    "sg_upload_haplotypes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
+    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_cdf_count_le",
+]
+
+
+class SgProfileCdf(C.Structure):
+    _fields_ = [("n_bases", C.c_int32), ("bases", C.c_char * 8), ("kmer", C.c_int32), ("bins", C.c_int32),
+                ("read_length", C.c_int32), ("n_qual", C.c_int32), ("min_qual", C.c_int32),
+                ("insert_rate", C.c_double), ("del_rate", C.c_double),
+                ("ins_cdf", C.POINTER(C.c_double)), ("n_ins", C.c_int32),
+                ("del_cdf", C.POINTER(C.c_double)), ("n_del", C.c_int32),
+                ("subs_cdf1", C.POINTER(C.c_double)), ("subs_cdf2", C.POINTER(C.c_double)),
+                ("qual_cdf", C.POINTER(C.c_double)), ("isize_cdf", C.POINTER(C.c_double)),
+                ("n_isize", C.c_int32), ("isize_min", C.c_int32), ("insert_size", C.c_int32)]
+
+
+class SgWindow(C.Structure):
+    _fields_ = [("hap_base", C.c_uint64), ("chain", C.c_uint32), ("spos", C.c_uint32), ("len", C.c_uint32),
+                ("n_reads", C.c_int32), ("seg", C.c_uint32), ("slot_base", C.c_uint32)]
+
+
+class SgBatch(C.Structure):
+    _fields_ = [("batch_id", C.c_uint32), ("paired", C.c_int32), ("name_prefix", C.c_char_p),
+                ("windows", C.POINTER(SgWindow)), ("n_windows", C.c_uint64),
+                ("seg_size", C.POINTER(C.c_uint32)), ("seg_first_window", C.POINTER(C.c_uint32)),
+                ("n_segs", C.c_uint32), ("first_window", C.c_uint32), ("first_slot", C.c_uint32)]
+
+
+class SgGcWindow(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("chain", C.c_uint32), ("len", C.c_uint32)]
+
+
+class SimuOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("has_seed", C.c_int32), ("seed", C.c_uint64), ("write_files", C.c_int32),
+                ("fetch", C.c_int32), ("quiet", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32)]
+
+
+class SimuStats(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("fragments", C.c_uint64), ("fastq_bytes", C.c_uint64),
+                ("planned_reads", C.c_uint64), ("windows", C.c_uint64), ("segments", C.c_uint64),
+                ("batches", C.c_uint64), ("t_load", C.c_double), ("t_haplotypes", C.c_double),
+                ("t_plan", C.c_double), ("t_sample", C.c_double), ("t_fetch", C.c_double),
+                ("t_write", C.c_double), ("t_total", C.c_double), ("kernel_ms", C.c_float * 8)]
+
+
+_engine = None
+_host = None
+
+
+def load_engine():
+    """dlopen libsimuscop_amd.so and declare the C ABI.  Raises if it has not been built."""
+    global _engine
+    if _engine is not None:
+        return _engine
+    if not os.path.exists(ENGINE_SO):
+        raise RuntimeError(f"{ENGINE_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP engine is the only compute path)")
+    lib = C.CDLL(ENGINE_SO, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.sg_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint64]
+    lib.sg_destroy.argtypes = [vp]
+    lib.sg_destroy.restype = None
+    lib.sg_last_error.argtypes = [vp]
+    lib.sg_last_error.restype = C.c_char_p
+    lib.sg_set_stream.argtypes = [vp, vp]
+    lib.sg_set_seed.argtypes = [vp, C.c_uint64]
+    lib.sg_load_profile.argtypes = [vp, C.POINTER(SgProfileCdf)]
+    lib.sg_upload_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.sg_plan.argtypes = [vp, C.POINTER(SgBatch)]
+    lib.sg_sample.argtypes = [vp]
+    lib.sg_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.sg_fetch.argtypes = [vp, vp, vp]
+    lib.sg_device_output.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.sg_gc_percent.argtypes = [vp, C.POINTER(SgGcWindow), C.c_uint64, C.POINTER(C.c_int32)]
+    lib.sg_set_profiling.argtypes = [vp, C.c_int]
+    lib.sg_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sg_cdf_count_le.argtypes = [C.c_double]
+    lib.sg_cdf_count_le.restype = C.c_uint64
+    _engine = lib
+    return lib
+
+
+def load_host():
+    """dlopen libsimuscop_host.so (C++ host side: config / profile / genome / driver)."""
+    global _host
+    if _host is not None:
+        return _host
+    load_engine()
+    if not os.path.exists(HOST_SO):
+        raise RuntimeError(f"{HOST_SO} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(HOST_SO, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.simu_default_options.argtypes = [C.POINTER(SimuOptions)]
+    lib.simu_default_options.restype = None
+    lib.simu_run.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(SimuStats), C.c_char_p, C.c_size_t]
+    lib.simu_open.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(vp), C.c_char_p, C.c_size_t]
+    lib.simu_close.argtypes = [vp]
+    lib.simu_close.restype = None
+    lib.simu_engine.argtypes = [vp]
+    lib.simu_engine.restype = vp
+    lib.simu_planned_reads.argtypes = [vp]
+    lib.simu_planned_reads.restype = C.c_uint64
+    lib.simu_chromosome_count.argtypes = [vp]
+    lib.simu_weighted_length.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+    lib.simu_set_reads.argtypes = [vp, C.c_int, C.c_int64, C.c_char_p, C.c_size_t]
+    lib.simu_prepare_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    lib.simu_get_stats.argtypes = [vp, C.POINTER(SimuStats)]
+    lib.simu_get_stats.restype = None
+    _host = lib
+    return lib
+
+
+class SimuError(RuntimeError):
+    pass
+
+
+def default_options(**kw) -> SimuOptions:
+    o = SimuOptions()
+    load_host().simu_default_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "seed":
+            o.has_seed, o.seed = 1, int(v)
+        elif k == "output_dir":
+            o.output_dir = v.encode() if isinstance(v, str) else v
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def run_config(config_path: str, **opts) -> SimuStats:
+    """`simuReads <config>` in-process (src/simuReads.cpp main)."""
+    lib = load_host()
+    o = default_options(**opts)
+    st = SimuStats()
+    err = C.create_string_buffer(4096)
+    rc = lib.simu_run(config_path.encode(), C.byref(o), C.byref(st), err, len(err))
+    if rc != 0:
+        raise SimuError(f"simuReads failed (exit code {rc}): {err.value.decode(errors='replace')}")
+    return st
+
+
+class Session:
+    """Step-by-step driver: inputs stay resident in HBM, the caller launches the sampling pass."""
+
+    def __init__(self, config_path: str, **opts):
+        self.lib = load_host()
+        self.eng = load_engine()
+        self._opts = default_options(**opts)
+        self._h = C.c_void_p()
+        self._err = C.create_string_buffer(4096)
+        rc = self.lib.simu_open(config_path.encode(), C.byref(self._opts), C.byref(self._h), self._err, len(self._err))
+        if rc != 0:
+            raise SimuError(self._err.value.decode(errors="replace"))
+        self.ctx = C.c_void_p(self.lib.simu_engine(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SimuError(self._err.value.decode(errors="replace"))
+
+    def _sg(self, rc, what):
+        if rc != 0:
+            raise SimuError(f"{what}: {self.eng.sg_last_error(self.ctx).decode(errors='replace')}")
+
+    @property
+    def planned_reads(self) -> int:
+        return int(self.lib.simu_planned_reads(self._h))
+
+    @property
+    def n_chromosomes(self) -> int:
+        return int(self.lib.simu_chromosome_count(self._h))
+
+    def weighted_length(self, popu: int = 0) -> float:
+        wl = C.c_double()
+        self._check(self.lib.simu_weighted_length(self._h, popu, C.byref(wl), self._err, len(self._err)))
+        return wl.value
+
+    def set_reads(self, reads: int, popu: int = 0) -> None:
+        self._check(self.lib.simu_set_reads(self._h, popu, int(reads), self._err, len(self._err)))
+
+    def prepare_batch(self, chrom: int = 0, popu: int = 0) -> bool:
+        hw = C.c_int()
+        self._check(self.lib.simu_prepare_batch(self._h, popu, chrom, C.byref(hw), self._err, len(self._err)))
+        return bool(hw.value)
+
+    def set_stream(self, stream_handle: int) -> None:
+        self._sg(self.eng.sg_set_stream(self.ctx, C.c_void_p(stream_handle)), "sg_set_stream")
+
+    def set_seed(self, seed: int) -> None:
+        self._sg(self.eng.sg_set_seed(self.ctx, int(seed)), "sg_set_seed")
+
+    def sample(self) -> None:
+        self._sg(self.eng.sg_sample(self.ctx), "sg_sample")
+
+    def result(self):
+        b1, b2, nf = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._sg(self.eng.sg_result(self.ctx, C.byref(b1), C.byref(b2), C.byref(nf)), "sg_result")
+        return b1.value, b2.value, nf.value
+
+    def kernel_times(self):
+        ms = (C.c_float * 8)()
+        self._sg(self.eng.sg_kernel_times(self.ctx, ms), "sg_kernel_times")
+        return {n: float(ms[i]) for i, n in enumerate(SG_K_NAMES)}
+
+    def fetch(self, n1: int, n2: int):
+        b1 = C.create_string_buffer(max(n1, 1))
+        b2 = C.create_string_buffer(max(n2, 1))
+        self._sg(self.eng.sg_fetch(self.ctx, b1, b2 if n2 else None), "sg_fetch")
+        return b1.raw[:n1], b2.raw[:n2]
+
+    def stats(self) -> SimuStats:
+        st = SimuStats()
+        self.lib.simu_get_stats(self._h, C.byref(st))
+        return st
+
+    def close(self):
+        if self._h:
+            self.lib.simu_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <functional>
 #include <memory>
 
 #include "../../../include/simuscop_amd.h"
@@ -169,7 +170,9 @@ struct Driver {
   }
 
   // one (population, chromosome): Genome.cpp:870-887
-  void run_batch(const std::string& popu, const std::string& chr, Sink& sink) {
+  // Builds the sampling plan of one (population, chromosome) and hands it to the engine (chains
+  // uploaded, sg_plan done).  Returns false when this process has nothing to sample in the batch.
+  bool prepare_batch(const std::string& popu, const std::string& chr) {
     ChromPlan& plan = genome.plans[popu][chr];
     const uint32_t bid = batch_id++;
     if (bid > 0xFFFF) throw Error("ERROR: more than 65535 (population, chromosome) batches");
@@ -211,7 +214,7 @@ struct Driver {
     st.windows += wins.size();
     st.segments += act.size();
     st.t_plan += since(t0);
-    if (wins.empty()) return;
+    if (wins.empty()) return false;
 
     // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
     size_t a0 = 0, a1 = act.size();
@@ -225,7 +228,7 @@ struct Driver {
         if (owner == opt.shard_rank) { if (!started) { a0 = i; started = true; } a1 = i + 1; }
         acc += act[i].slots;
       }
-      if (!started) return;
+      if (!started) return false;
     }
     const uint32_t w_lo = act[a0].w_first;
     const uint32_t w_hi = a1 < act.size() ? act[a1].w_first : (uint32_t)wins.size();
@@ -252,6 +255,14 @@ struct Driver {
     b.first_window = w_lo;
     b.first_slot = slot_lo;
     eng.check(sg_plan(eng.ctx, &b), "sg_plan");
+    st.t_sample += since(t0);
+    return true;
+  }
+
+  void run_batch(const std::string& popu, const std::string& chr, Sink& sink) {
+    if (!prepare_batch(popu, chr)) return;
+    const bool paired = cfg.paired();
+    auto t0 = Clock::now();
     uint64_t n1 = 0, n2 = 0, nf = 0;
     const int reps = opt.repeat_sample > 1 ? opt.repeat_sample : 1;
     for (int r = 0; r < reps; r++) {
@@ -280,14 +291,16 @@ struct Driver {
     }
   }
 
-  void run(const std::string& config_path) {
-    auto t_all = Clock::now();
+  Clock::time_point t_all;
+  void open(const std::string& config_path) {
+    t_all = Clock::now();
     auto t0 = Clock::now();
     cfg.load(config_path);
     seed = opt.has_seed ? opt.seed : (uint64_t)cfg.num["seed"];
     genome.load_data();
     const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
     if (opt.write_files) mkdir(out_dir.c_str(), 0755);  // src/simuReads.cpp:56-60
+    (void)out_dir;
     const int device = opt.device >= 0 ? opt.device : (int)cfg.num["device"];
     if (sg_create(&eng.ctx, device, seed) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(nullptr));
     sg_set_profiling(eng.ctx, 1);
@@ -297,11 +310,15 @@ struct Driver {
     eng.check(sg_load_profile(eng.ctx, &view), "sg_load_profile");
     genome.generate_segments();
     st.t_load = since(t0);
+    st.planned_reads = (uint64_t)(genome.target_length() * cfg.num["coverage"] / prof.read_length);
+  }
 
+  void run(const std::string& config_path) {
+    open(config_path);
+    const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
     // Genome::yieldReads
     const std::vector<std::string>& popus = cfg.popu_names;
-    const long reads = genome.target_length() * cfg.num["coverage"] / prof.read_length;
-    st.planned_reads = (uint64_t)reads;
+    const long reads = (long)st.planned_reads;
     if (cfg.verbose()) log("\nNumber of reads to sample: " + std::to_string(reads) + "\n");
     std::map<std::string, double> acn;  // Genome::calculateACNs, Genome.cpp:765-781
     for (auto& pp : genome.plans) {
@@ -373,3 +390,59 @@ extern "C" int simu_run(const char* config_path, const simu_options* opt, simu_s
     return 1;
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Session API: the same driver, opened step by step so that a caller (bench.py, a multi-GPU
+// launcher) can keep the inputs resident in HBM and drive sg_sample on its own stream.
+// ------------------------------------------------------------------------------------------------
+struct simu_session { simu::Driver d; };
+
+static int session_guard(char* err, size_t err_len, const std::function<void()>& fn) {
+  try { fn(); return 0; }
+  catch (const simu::Error& e) { if (err && err_len) { strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; } return e.exit_code ? e.exit_code : 1; }
+  catch (const std::exception& e) { if (err && err_len) { strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; } return 1; }
+}
+
+extern "C" int simu_open(const char* config_path, const simu_options* opt, simu_session** out, char* err, size_t err_len) {
+  if (!out) return 1;
+  *out = nullptr;
+  std::unique_ptr<simu_session> s(new simu_session());
+  if (opt) s->d.opt = *opt; else simu_default_options(&s->d.opt);
+  if (s->d.opt.shard_world < 1) s->d.opt.shard_world = 1;
+  int rc = session_guard(err, err_len, [&]() { s->d.open(config_path ? config_path : ""); });
+  if (rc == 0) *out = s.release();
+  return rc;
+}
+extern "C" void simu_close(simu_session* s) { delete s; }
+extern "C" void* simu_engine(simu_session* s) { return s ? (void*)s->d.eng.ctx : nullptr; }
+extern "C" uint64_t simu_planned_reads(simu_session* s) { return s->d.st.planned_reads; }
+extern "C" int simu_chromosome_count(simu_session* s) { return (int)s->d.genome.chromosomes.size(); }
+// Sum over this session's chromosomes of the GC-weighted length of population `popu`
+// (Genome::setReadCounts' WL, Genome.cpp:787-797).  Runs pass 1 (haplotypes + GPU GC scan) on first use.
+extern "C" int simu_weighted_length(simu_session* s, int popu, double* wl, char* err, size_t err_len) {
+  return session_guard(err, err_len, [&]() {
+    simu::Driver& d = s->d;
+    const std::string& p = d.cfg.popu_names.at(popu);
+    double WL = 0;
+    for (const std::string& chr : d.genome.chromosomes) {
+      d.weigh(p, chr);
+      simu::ChromPlan& plan = d.genome.plans[p][chr];
+      double c = 0;
+      for (const simu::Segment& g : plan.segs) c += simu::Driver::seg_weight(plan, g);
+      WL += c;
+    }
+    *wl = WL;
+  });
+}
+extern "C" int simu_set_reads(simu_session* s, int popu, int64_t reads, char* err, size_t err_len) {
+  return session_guard(err, err_len, [&]() { s->d.set_read_counts(s->d.cfg.popu_names.at(popu), (long)reads); });
+}
+// Upload the chromosome's haplotype chains and hand its sampling plan to the engine.  `has_work`
+// is 0 when this shard has nothing to sample there.
+extern "C" int simu_prepare_batch(simu_session* s, int popu, int chr, int* has_work, char* err, size_t err_len) {
+  return session_guard(err, err_len, [&]() {
+    bool w = s->d.prepare_batch(s->d.cfg.popu_names.at(popu), s->d.genome.chromosomes.at(chr));
+    if (has_work) *has_work = w ? 1 : 0;
+  });
+}
+extern "C" void simu_get_stats(simu_session* s, simu_stats* st) { if (s && st) *st = s->d.st; }

@@ -42,6 +42,18 @@ int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats
 
 void simu_default_options(simu_options* opt);
 
+// ---- step-by-step session (bench.py / multi-GPU launcher) ----
+typedef struct simu_session simu_session;
+int simu_open(const char* config_path, const simu_options* opt, simu_session** out, char* err, size_t err_len);
+void simu_close(simu_session* s);
+void* simu_engine(simu_session* s);  // the sg_ctx* of this session
+uint64_t simu_planned_reads(simu_session* s);
+int simu_chromosome_count(simu_session* s);
+int simu_weighted_length(simu_session* s, int popu, double* wl, char* err, size_t err_len);
+int simu_set_reads(simu_session* s, int popu, int64_t reads, char* err, size_t err_len);
+int simu_prepare_batch(simu_session* s, int popu, int chr, int* has_work, char* err, size_t err_len);
+void simu_get_stats(simu_session* s, simu_stats* st);
+
 #ifdef __cplusplus
 }
 #endif
