@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@ void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s);
+void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
 }  // namespace sg
 
@@ -162,6 +164,11 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   if (pr->n_bases != 4) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: only 4-letter base alphabets are supported");
   if (pr->kmer < 1 || pr->kmer > 6) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: kmer must be in 1..6");
   if (pr->bins < 1 || pr->read_length < 1 || pr->read_length > 30000) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad bins/read_length");
+  {  // the kernels compute bin = i*bins/n' with a 32-bit reciprocal: exact while i*bins*n' < 2^32
+    const uint64_t npmax = (uint64_t)pr->read_length + (uint64_t)SG_MAX_EVENTS * (uint64_t)(pr->n_ins > 0 ? pr->n_ins : 1);
+    if (npmax > 0xFFFF || npmax * (uint64_t)pr->bins * npmax >= (1ull << 32))
+      return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: read_length * bins too large for the 32-bit bin arithmetic");
+  }
   if (pr->n_qual < 1 || pr->n_qual > 4096) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad n_qual");
   if (!pr->subs_cdf1 || !pr->qual_cdf || !pr->ins_cdf || !pr->del_cdf || pr->n_ins < 1 || pr->n_del < 1)
     return ctx->fail(SG_ERR_INVALID, "sg_load_profile: missing table");
@@ -194,21 +201,26 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     const double* src = t == 0 ? pr->subs_cdf1 : pr->subs_cdf2;
     for (size_t r = 0; r < sub_rows; r++) sg::encode_sub_row(src + r * 4, &tab[(t * sub_rows + r) * 4]);
   }
-  // quality rows
+  // quality rows, compacted to the symbols that carry probability mass (XTen: 7 of 94)
   const size_t qrows = (size_t)16 * bins;
-  std::vector<sg::Row> qr(qrows);
-  uint32_t wmax = 1;
+  std::vector<sg::CompactRow> qr(qrows);
+  uint32_t wmax = 4;
   for (size_t r = 0; r < qrows; r++) {
-    qr[r] = sg::encode_row(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
+    qr[r] = sg::encode_compact_row(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
     if (qr[r].T.size() > wmax) wmax = (uint32_t)qr[r].T.size();
   }
-  const uint32_t qW = sg::pow2_at_least(wmax), qstride = qW + 1;
+  const uint32_t qW = sg::pow2_at_least(wmax), qstride = qW + qW / 4;
   const size_t qual_off = tab.size();
   tab.resize(qual_off + qrows * qstride, 0xFFFFFFFFu);
   for (size_t r = 0; r < qrows; r++) {
     uint32_t* row = &tab[qual_off + r * qstride];
-    row[0] = qr[r].k0;
-    for (size_t i = 0; i < qr[r].T.size(); i++) row[1 + i] = qr[r].T[i];
+    const sg::CompactRow& cr = qr[r];
+    for (size_t i = 0; i < cr.T.size(); i++) row[i] = cr.T[i];
+    for (uint32_t i = 0; i < qW; i++) {
+      const uint32_t sym = cr.sym[i < cr.sym.size() ? i : cr.sym.size() - 1];
+      uint32_t& w = row[qW + i / 4];
+      w = (w & ~(0xFFu << (8 * (i % 4)))) | (sym << (8 * (i % 4)));
+    }
   }
   auto add_row = [&](const double* cdf, int n, size_t& off, uint32_t& lg) {
     sg::Row r = sg::encode_row(cdf, n);
@@ -268,9 +280,9 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
 int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chains, const uint64_t* lens) {
   if (!ctx || n_chains < 0 || (n_chains && (!chains || !lens))) return SG_ERR_INVALID;
   SG_HIP(hipSetDevice(ctx->device));
-  const size_t PAD = 64;
+  const size_t PAD = 256;  // front/back guard: kernels read up to 16 bytes around a fragment
   std::vector<uint64_t> meta(2 * (size_t)n_chains + 2, 0);  // [off..., len...]
-  size_t total = 0;
+  size_t total = PAD;  // front pad: the emit kernel reads up to 11 bytes before a fragment start
   for (int c = 0; c < n_chains; c++) {
     meta[c] = total;
     meta[n_chains + c] = lens[c];
@@ -279,10 +291,14 @@ int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chain
   total += PAD;
   SG_ENSURE(ctx->chains, total);
   SG_ENSURE(ctx->chain_meta, meta.size() * 8);
+  total = (total + 15) & ~(size_t)15;
   SG_HIP(hipMemsetAsync(ctx->chains.p, 'N', total, ctx->stream));
   for (int c = 0; c < n_chains; c++)
     if (lens[c]) SG_HIP(hipMemcpyAsync((uint8_t*)ctx->chains.p + meta[c], chains[c], lens[c], hipMemcpyHostToDevice, ctx->stream));
   SG_HIP(hipMemcpyAsync(ctx->chain_meta.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  // ASCII -> base codes, in place (A0 C1 T2 G3, N=4, other=5): the kernels never see ASCII
+  sg::launch_encode((uint8_t*)ctx->chains.p, total, ctx->stream);
+  SG_HIP(hipGetLastError());
   SG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->B.chains = ctx->chains.as<uint8_t>();
   ctx->B.chain_off = ctx->chain_meta.as<uint64_t>();
@@ -389,6 +405,7 @@ static int run_pass(sg_ctx* ctx) {
   sg::DevBatch& B = ctx->B;
   B.k0 = (uint32_t)ctx->seed;
   B.k1 = (uint32_t)(ctx->seed >> 32);
+  { const char* dg = getenv("SG_DIAG"); B.diag = dg ? (uint32_t)atoi(dg) : 0u; }
   hipStream_t s = ctx->stream;
   const bool prof = ctx->profiling;
   SG_HIP(hipMemsetAsync(B.totals, 0, 4 * 8, s));

@@ -24,7 +24,7 @@ __host__ __device__ inline uint32_t ev_pack(uint32_t j, uint32_t len, uint32_t d
 struct DevProfile {
   const uint4* sub;            // [mate][kmer_count][bins] rows {T0,T1,T2,k0}
   uint32_t sub_mate_rows;      // rows per mate table (0 when mate 2 shares mate 1's table)
-  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {k0, T0..T(W-1)}
+  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {T0..T(W-1), sym bytes packed 4 per word}, W = 1<<qual_lg
   uint32_t qual_stride, qual_lg;
   const uint32_t* ins_row; uint32_t ins_lg;
   const uint32_t* del_row; uint32_t del_lg;
@@ -54,6 +54,7 @@ struct DevBatch {
   const uint8_t* prefix;        // "@popu#chr#"
   uint32_t prefix_len;
   uint32_t k0, k1;              // philox key
+  uint32_t diag;                // SG_DIAG timing ablations (0 in production; outputs are wrong otherwise)
   // work buffers
   PairRec* pairs;               // [n_slots]
   uint32_t* win_actual;         // [n_windows] fragments actually produced per window

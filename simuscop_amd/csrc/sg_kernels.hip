@@ -14,6 +14,8 @@
 //   emit_kernel      Profile::predict sampling loop  (Profile.cpp:1636-1700) + FASTQ formatting
 //                    (Segment.cpp:803-832)
 //   gc_kernel        calculateGCPercent              (lib/mydefine/MyDefine.cpp:279-303)
+#include <algorithm>
+
 #include "sg_device.h"
 
 namespace sg {
@@ -26,8 +28,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
@@ -49,6 +52,15 @@ __device__ __forceinline__ uint32_t row_search(const uint32_t* __restrict__ row,
   for (uint32_t step = lg ? (1u << (lg - 1)) : 0; step; step >>= 1)
     if (x > T[pos + step - 1]) pos += step;
   return row[0] + pos;
+}
+
+// quality row {T0..T(W-1), sym bytes}: symbol of the first threshold >= x
+__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ row, uint32_t lg, uint32_t x) {
+  uint32_t pos = 0;
+  for (uint32_t step = lg ? (1u << (lg - 1)) : 0; step; step >>= 1)
+    if (x > row[pos + step - 1]) pos += step;
+  const uint32_t w = row[(1u << lg) + (pos >> 2)];
+  return (w >> (8u * (pos & 3u))) & 0xFFu;
 }
 
 __device__ __forceinline__ uint32_t aux_draw(const DevBatch& B, uint32_t slot, uint32_t j, uint32_t f, uint32_t mate) {
@@ -275,163 +287,335 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// emit: one lane per read; samples substitution + quality per base and writes the FASTQ record
+// emit: Profile::predict's sampling loop (Profile.cpp:1636-1700) + FASTQ formatting
+// (Segment.cpp:803-832).
+//
+// Mapping (v3).  A wave owns G consecutive reads of one mate (one contiguous ~21 KB output range).
+//   phase 0  lane = read: gather its metadata into a 32-byte LDS row and write the record's header text.
+//   phase 1  lane = 8 consecutive bases.  The lane -> (read-in-iteration, item) map is FIXED:
+//            TI = ceil((L+3)/8) items per read, RPI = 64/TI reads per wave iteration, so there is no
+//            search, no division and no shuffle in the loop; read metadata comes from two LDS b128
+//            reads.  Consecutive lanes write consecutive 8-byte runs: whole cache lines per store.
+//            Reads grown by insertions beyond 8*TI-3 bases finish in a short clean-up loop.
+// Haplotypes arrive pre-encoded (encode_kernel: A0 C1 T2 G3, N=4, other=5), thresholds live in LDS,
+// sampling is branch-free integer compares.  v1 (lane per read) wrote each line in 32 partial
+// stores (35.8 GB fabric writes for 4.2 GB of FASTQ); v2 fixed the traffic but spent ~1100
+// instructions per 4 bases on bookkeeping (profiles/README.md).
 // ------------------------------------------------------------------------------------------------
-struct Packer {  // byte stream -> unaligned dword stores
-  uint8_t* p;
-  uint32_t w, nb;
-  __device__ __forceinline__ void init(uint8_t* dst) { p = dst; w = 0; nb = 0; }
-  __device__ __forceinline__ void push(uint32_t b) {
-    w |= b << (nb * 8);
-    if (++nb == 4) {
-      __builtin_memcpy(p, &w, 4);
-      p += 4; w = 0; nb = 0;
-    }
-  }
-  __device__ __forceinline__ void flush() {
-    for (uint32_t i = 0; i < nb; i++) p[i] = (uint8_t)(w >> (8 * i));
-    p += nb; nb = 0; w = 0;
-  }
-  __device__ __forceinline__ void push_dec(uint32_t v) {
-    uint32_t nd = ndigits(v);
-    uint32_t div = 1;
-    for (uint32_t i = 1; i < nd; i++) div *= 10;
-    for (uint32_t i = 0; i < nd; i++) {
-      uint32_t d = v / div;
-      push('0' + d);
-      v -= d * div;
-      div /= 10;
-    }
-  }
-};
+#define EMIT_THREADS 1024
+#define EMIT_WAVES (EMIT_THREADS / 64)
+#define META_ROW 32  // bytes of LDS metadata per read
 
-__global__ __launch_bounds__(256) void emit_kernel(DevProfile P, DevBatch B) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t m = blockIdx.y;
-  if (t >= B.n_slots) return;
-  const PairRec rec = B.pairs[t];
-  const uint32_t flen = rec.fl & 0x7FFFFFFFu;
-  if (!flen) return;
-  const size_t idx = (size_t)m * B.n_slots + t;
-  const uint64_t off = B.recoff[idx];
-  const uint32_t rl = B.rlen[idx];
-  const uint32_t np = rl & 0xFFFFu;
-  const uint32_t nev = rl >> 16;
-  if (off + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
-  const sg_window win = B.windows[rec.win];
-  const uint32_t pos = win.spos + rec.relpos;
-  const uint8_t* frag = B.chains + B.chain_off[win.chain] + win.hap_base + pos;
-  const bool rev = B.paired ? (m == 1) : ((rec.fl >> 31) != 0);
-  const uint32_t tm = B.paired ? m : 0u;  // SE always samples from the mate-1 tables (Segment.cpp:770,777)
-  const uint32_t L = (uint32_t)P.L;
+// Orders one wave's LDS writes before its later LDS reads by other lanes (wave-private staging rows).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
-  // ---- header: @popu#chr#pos%segsize#fragCount[/m]\n  (Segment.cpp:780,809,824) ----
-  uint8_t* o = B.out[m] + off;
-  Packer ps;
-  ps.init(o);
-  for (uint32_t i = 0; i < B.prefix_len; i++) ps.push(B.prefix[i]);
-  const uint32_t namepos = pos % B.seg_size[win.seg];
-  const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-  ps.push_dec(namepos);
-  ps.push('#');
-  ps.push_dec(fragcount);
-  if (B.paired) { ps.push('/'); ps.push('1' + m); }
-  ps.push('\n');
-  const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
-  Packer pq;
-  pq.init(o + hdr + np + 3u);
-
-  // ---- event cursor ----
-  const uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
+// Source codes of a read that carries sequencing-indel events (rare path, kept OUT OF LINE and
+// un-unrolled: inlined it pushed the kernel past the 64 KB instruction cache and cost 2x).
+// Walks the events of Profile::predict's first loop (Profile.cpp:1607-1658) with a forward cursor and
+// returns 13 nibbles, one per output position p = i0-5+q: base code 0..3 (template bases complemented
+// for reverse reads), 4/5 = not in `bases`, bit 3 set = inserted base (already a profile code).
+__device__ __noinline__ uint64_t slow_codes(const uint8_t* frag, uint32_t flen, uint32_t rev, const uint32_t* ev,
+                                            uint32_t nev, uint32_t np, uint32_t i0, uint32_t K, uint32_t slot,
+                                            uint32_t ctx_aux, uint32_t k0, uint32_t k1) {
+  uint64_t out = 0;
   uint32_t e = 0;
-  uint32_t nextw = nev ? ev[0] : 0xFFFFFFFFu;  // j field 0xFFFF never matches (L < 65535)
-  uint32_t ins_left = 0, ins_j = 0, ins_f = 1;
+  int shift = 0;  // output index - template index of the template bases after the consumed events
+  uint32_t nextw = nev ? ev[0] : 0xFFFFFFFFu;
+  const uint32_t revmask = rev ? 2u : 0u;
+#pragma unroll 1
+  for (int q = 0; q < 13; q++) {
+    const int p = (int)i0 - 5 + q;
+    uint32_t v = 4u;
+    if (p >= 0 && (uint32_t)p < np && q >= 6 - (int)K) {
+      // consume the events that end before p
+#pragma unroll 1
+      while (nextw != 0xFFFFFFFFu) {
+        const int j = (int)(nextw & 0xFFFFu), len = (int)((nextw >> 16) & 0x7FFFu);
+        const int pe = j + shift;  // output position of template base j / where it would have been
+        if (nextw >> 31) { if (p < pe) break; shift -= len; }
+        else { if (p <= pe + len) break; shift += len; }
+        e++;
+        nextw = e < nev ? ev[e] : 0xFFFFFFFFu;
+      }
+      bool inserted = false;
+      if (nextw != 0xFFFFFFFFu && !(nextw >> 31)) {
+        const int j = (int)(nextw & 0xFFFFu);
+        const int pe = j + shift;
+        if (p > pe) {  // inserted base number p-pe: randomInteger(0, N-1), never the last base (Profile.cpp:1564)
+          const uint32_t f = (uint32_t)(p - pe);
+          uint32_t x[4];
+          philox4x32_10(slot, (uint32_t)j, f >> 2, ctx_aux, k0, k1, x);
+          const uint32_t l = f & 3u;
+          const uint32_t xv = l == 0 ? x[0] : l == 1 ? x[1] : l == 2 ? x[2] : x[3];
+          v = 8u | __umulhi(xv, 3u);
+          inserted = true;
+        }
+      }
+      if (!inserted) {
+        const uint32_t jt = (uint32_t)(p - shift);
+        v = ((uint32_t)frag[rev ? flen - 1u - jt : jt] ^ revmask) & 7u;
+      }
+    }
+    out |= (uint64_t)v << (4 * q);
+  }
+  return out;
+}
 
-  // ---- source walk state ----
-  uint32_t j = 0;                         // next reference position of the L-base read template
-  uint32_t cw = 0, cidx = 0xFFFFFFFFu;    // cached 4 haplotype bytes
-  const uint32_t K = (uint32_t)P.kmer;
-  const uint32_t ctxmask = (1u << (2 * K)) - 1u;
-  uint32_t ctxv = 0, vc = 0;
-  uint32_t bin = 0, acc = 0;              // bin = i*bins/np, acc = i*bins - bin*np
+// One item = output positions [8c, 8c+8) of one read: sample and store bases + qualities.
+//   m0 = {frag_lo, frag_hi, out_lo, out_hi}   m1 = {flen | rev<<31, np | nev<<16 | hdr<<20, inv, -}
+template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
+__device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
+                                          const uint32_t* lds_qual, const uint4* gsub, uint32_t m, const uint4 m0,
+                                          const uint4 m1, uint32_t slot, uint32_t c, bool active) {
+  const uint32_t K = KT ? (uint32_t)KT : (uint32_t)P.kmer;
   const uint32_t bins = (uint32_t)P.bins;
-  const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
-  const uint4* subt = P.sub + (size_t)tm * P.sub_mate_rows;
+  const uint32_t ctxmask = (1u << (2 * K)) - 1u;
+  const uint32_t flen = m1.x & 0x7FFFFFFFu;
+  const bool rev = (m1.x >> 31) != 0;
+  const uint32_t np = m1.y & 0xFFFFu, nev = (B.diag & 32u) ? 0u : ((m1.y >> 16) & 0xFu), hdr = m1.y >> 20;
+  const uint32_t inv = m1.z;
+  const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
+  const uint32_t i0 = 8u * c;
+  const uint32_t revmask = rev ? 2u : 0u;  // complement in code space: A0<->T2, C1<->G3 (Segment.cpp:81-103)
 
-  for (uint32_t i0 = 0; i0 < np; i0 += 2) {
-    uint32_t x[4];
-    philox4x32_10(t + B.slot_offset, i0 >> 1, 0, c3b, B.k0, B.k1, x);
+  // ---- source codes for positions i0-5 .. i0+7 (index q = p - i0 + 5); >= 4 means "not in bases" ----
+  uint32_t code[13];
+  if (nev == 0) {
+    // 16 encoded haplotype bytes; after the conditional byte reversal position p sits at byte p-i0+5
+    // unused slots (flen == 0: last partial group, abandoned windows) read a harmless in-bounds address
+    const uint8_t* src = flen == 0u ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
+    uint32_t w[4] = {0x00010203u + i0, 0x03020100u, 0x01000302u, 0x02030001u};
+    if (!(B.diag & 2u)) __builtin_memcpy(w, src, 16);
+    if (rev) {
+      const uint32_t t0 = __builtin_bswap32(w[3]), t1 = __builtin_bswap32(w[2]);
+      const uint32_t t2 = __builtin_bswap32(w[1]), t3 = __builtin_bswap32(w[0]);
+      w[0] = t0; w[1] = t1; w[2] = t2; w[3] = t3;
+    }
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const uint32_t i = i0 + h;
-      if (i >= np) break;
-      const uint32_t xs = x[2 * h], xq = x[2 * h + 1];
-      // -- next source base: profile code 0..3, or 4 = not in `bases` --
-      uint32_t code;
-      if (ins_left) {
-        code = __umulhi(aux_draw(B, t, ins_j, ins_f, m), 3u);  // randomInteger(0, N-1): never the last base
-        ins_f++;
-        ins_left--;
-      } else {
-        while ((nextw & 0xFFFFu) == j && (nextw >> 31)) {      // deletion(s) starting here
-          j += (nextw >> 16) & 0x7FFFu;
-          e++;
-          nextw = e < nev ? ev[e] : 0xFFFFFFFFu;
-        }
-        const uint32_t f = rev ? flen - 1u - j : j;
-        const uint32_t widx = f >> 2;
-        if (widx != cidx) {
-          __builtin_memcpy(&cw, frag + (size_t)widx * 4, 4);
-          cidx = widx;
-        }
-        const uint32_t byte = (cw >> ((f & 3u) * 8u)) & 0xFFu;
-        const bool valid = (byte == 'A') | (byte == 'C') | (byte == 'G') | (byte == 'T');
-        uint32_t nat = (byte >> 1) & 3u;   // A0 C1 T2 G3
-        if (rev) nat ^= 2u;                 // complement (Segment.cpp:81-103)
-        code = valid ? ((P.remap_packed >> (2u * nat)) & 3u) : 4u;
-        if ((nextw & 0xFFFFu) == j) {      // insertion after this base
-          ins_left = (nextw >> 16) & 0x7FFFu;
-          ins_j = j;
-          ins_f = 1;
-          e++;
-          nextw = e < nev ? ev[e] : 0xFFFFFFFFu;
-        }
-        j++;
-      }
-      // -- k-mer context ending at i (Profile::initKmers order, Profile.cpp:70-124) --
-      const bool valid = code < 4u;
-      ctxv = ((ctxv << 2) | (code & 3u)) & ctxmask;
-      vc = valid ? min(vc + 1u, K) : 0u;
-      const uint32_t mlen = min(i + 1u, K);
-      int k;
-      if (vc >= mlen) {
-        const uint32_t kidx = P.kmer_off[mlen] + (ctxv & ((1u << (2u * mlen)) - 1u));
-        const uint4 row = subt[(size_t)kidx * bins + bin];
-        uint32_t c = (xs > row.x) + (xs > row.y) + (xs > row.z);
-        k = (int)max(c, row.w);
-      } else {
-        k = valid ? (int)code : -1;
-      }
-      uint32_t ch, q;
-      if (k >= 0) {
-        ch = (P.bases_packed >> (8u * (uint32_t)k)) & 0xFFu;
-        const uint32_t bp = code * 4u + (uint32_t)k;
-        q = (uint32_t)P.min_qual + row_search(P.qual + (size_t)(bp * bins + bin) * P.qual_stride, P.qual_lg, xq);
-      } else {
-        ch = 'N';
-        q = (uint32_t)P.min_qual + __umulhi(xq, 20u);  // getRandBaseQuality, Profile.cpp:1582-1584
-      }
-      ps.push(ch);
-      pq.push(q);
-      acc += bins;
-      while (acc >= np) { acc -= np; bin++; }
+    for (int q = 0; q < 13; q++) code[q] = ((w[q >> 2] >> ((q & 3) * 8)) & 0xFFu) ^ revmask;
+  } else {
+    const uint32_t* ev = B.events + ((size_t)m * B.n_slots + slot) * SG_MAX_EVENTS;
+    const uint64_t packed = slow_codes(frag, flen, rev ? 1u : 0u, ev, nev, np, i0, K, slot + B.slot_offset,
+                                       dev_ctx(KIND_AUX, m, B.batch_id), B.k0, B.k1);
+#pragma unroll
+    for (int q = 0; q < 13; q++) {
+      const uint32_t v = (uint32_t)(packed >> (4 * q)) & 0xFu;
+      code[q] = (v & 8u) ? (0x100u | (v & 3u)) : v;
     }
   }
-  ps.push('\n'); ps.push('+'); ps.push('\n');
-  ps.flush();
-  pq.push('\n');
-  pq.flush();
-  (void)L;
+  // natural index (A0 C1 T2 G3) -> profile base code; inserted bases (0x100 flag) already are profile codes
+  const bool identity = P.remap_packed == 0xE4u;
+#pragma unroll
+  for (int q = 0; q < 13; q++) {
+    uint32_t v = code[q];
+    if (v & 0x100u) v &= 3u;
+    else if (!identity && v < 4u) v = (P.remap_packed >> (2u * v)) & 3u;
+    code[q] = v;
+  }
+  // ---- k-mer context of the K-1 positions before i0 (Profile::initKmers order, Profile.cpp:70-124) ----
+  uint32_t ctxv = 0, vc = 0;
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    if (q >= 6 - (int)K && (int)i0 - 5 + q >= 0) {
+      const bool valid = code[q] < 4u;
+      ctxv = ((ctxv << 2) | (code[q] & 3u)) & ctxmask;
+      vc = valid ? min(vc + 1u, K) : 0u;
+    }
+  }
+  // ---- four Philox calls: [sub, qual] for 8 bases (counter = i/2) ----
+  uint32_t x[16];
+  const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    if (B.diag & 8u) { for (int z = 0; z < 4; z++) x[4 * h + z] = (slot * 2654435761u) ^ (c * 40503u + (4 * h + z) * 0x9E3779B9u); }
+    else philox4x32_10(slot + B.slot_offset, 4u * c + (uint32_t)h, 0, c3b, B.k0, B.k1, x + 4 * h);
+  }
+  uint32_t sw[2] = {0, 0}, qw[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    const uint32_t i = i0 + (uint32_t)h;
+    const uint32_t cd = code[5 + h];
+    const bool valid = cd < 4u;
+    ctxv = ((ctxv << 2) | (cd & 3u)) & ctxmask;
+    vc = valid ? min(vc + 1u, K) : 0u;
+    const uint32_t xs = x[2 * h], xq = x[2 * h + 1];
+    const uint32_t bin = min(__umulhi(i * bins, inv), bins - 1u);  // i*binCount/n' (clamp only guards idle lanes)
+    const uint32_t mlen = min(i + 1u, K);
+    const uint32_t mmask = (1u << (2u * mlen)) - 1u;
+    const bool ctx_ok = vc >= mlen && !(B.diag & 16u);
+    // contexts with m real bases start at (4^m-4)/3 = (0x55555555 & (4^m-1)) - 1
+    const uint32_t kidx = ctx_ok ? ((0x55555555u & mmask) - 1u) + (ctxv & mmask) : 0u;
+    const uint4 row = SUB_LDS ? lds_sub[kidx * bins + bin] : gsub[(size_t)kidx * bins + bin];
+    const uint32_t cnt = (xs > row.x) + (xs > row.y) + (xs > row.z);
+    const uint32_t k = ctx_ok ? max(cnt, row.w) : cd;  // unknown context: the base is copied (Profile.cpp:1531-1533)
+    const bool kvalid = k < 4u;
+    const uint32_t kk = kvalid ? k : 0u;
+    const uint32_t rowi = (((valid ? cd : 0u) * 4u + kk) * bins + bin) * P.qual_stride;
+    const uint32_t* qrow = QUAL_LDS ? lds_qual + rowi : P.qual + rowi;
+    uint32_t qi;
+    if (B.diag & 16u) qi = 7u + (xq >> 29);
+    else if (QLG == 3) {  // 8-wide row: three probes, then the symbol byte
+      uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
+      pos += (xq > qrow[pos + 1]) ? 2u : 0u;
+      pos += (xq > qrow[pos]) ? 1u : 0u;
+      qi = (qrow[8 + (pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+    } else {
+      qi = qual_lookup(qrow, P.qual_lg, xq);
+    }
+    uint32_t ch = kvalid ? ((P.bases_packed >> (8u * kk)) & 0xFFu) : (uint32_t)'N';
+    uint32_t q = (uint32_t)P.min_qual + (kvalid ? qi : __umulhi(xq, 20u));  // getRandBaseQuality, Profile.cpp:1582-1584
+    if (i >= np) {  // "\n+\n" after the bases, '\n' after the qualities
+      ch = (i - np == 1u) ? '+' : '\n';
+      q = '\n';
+    }
+    sw[h >> 2] |= ch << (8 * (h & 3));
+    qw[h >> 2] |= q << (8 * (h & 3));
+  }
+  if (active && !(B.diag & 1u)) {
+    uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
+    uint8_t* qo = so + np + 3u;
+    const uint32_t ns = min(8u, np + 3u - i0);                  // bases + "\n+\n"
+    const uint32_t nq = i0 <= np ? min(8u, np + 1u - i0) : 0u;  // qualities + '\n'
+    if (ns == 8) __builtin_memcpy(so, sw, 8);
+    else for (uint32_t b2 = 0; b2 < ns; b2++) so[b2] = (uint8_t)(sw[b2 >> 2] >> (8 * (b2 & 3)));
+    if (nq == 8) __builtin_memcpy(qo, qw, 8);
+    else for (uint32_t b2 = 0; b2 < nq; b2++) qo[b2] = (uint8_t)(qw[b2 >> 2] >> (8 * (b2 & 3)));
+  }
+}
+
+template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
+                                                            uint32_t TI, uint32_t RPI) {
+  extern __shared__ uint4 smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t m = blockIdx.y;
+  const uint32_t tm = B.paired ? m : 0u;  // SE always samples from the mate-1 tables (Segment.cpp:770,777)
+  // ---- LDS carve-up: [sub rows][qual words][per-wave metadata rows] ----
+  uint4* lds_sub = smem;
+  uint32_t* lds_qual = (uint32_t*)(smem + (SUB_LDS ? sub_rows : 0u));
+  uint4* lds_meta_all = (uint4*)(lds_qual + (QUAL_LDS ? ((qual_words + 3u) & ~3u) : 0u));
+  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
+  if (SUB_LDS)
+    for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) lds_sub[i] = gsub[i];
+  if (QUAL_LDS)
+    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) lds_qual[i] = P.qual[i];
+  __syncthreads();
+  uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
+
+  const uint32_t G = RPI * (64u / RPI);             // reads per wave group
+  const uint32_t ngroups = (B.n_slots + G - 1u) / G;
+  const uint32_t sub = lane / TI, c_lane = lane - sub * TI;  // fixed lane -> (read in iteration, item)
+  const bool lane_ok = sub < RPI;
+
+  for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
+    // ================= phase 0: lane = read =================
+    const uint32_t t = g * G + lane;
+    uint32_t items = 0;
+    uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
+    if (lane < G && t < B.n_slots) {
+      const PairRec rec = B.pairs[t];
+      const uint32_t flen = rec.fl & 0x7FFFFFFFu;
+      if (flen) {
+        const size_t idx = (size_t)m * B.n_slots + t;
+        const uint32_t rl = B.rlen[idx];
+        const uint32_t np = rl & 0xFFFFu, nev = rl >> 16;
+        const sg_window win = B.windows[rec.win];
+        const uint32_t pos = win.spos + rec.relpos;
+        const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
+        const bool rev = B.paired ? (m == 1) : ((rec.fl >> 31) != 0);
+        const uint64_t ooff = B.recoff[idx];
+        const uint32_t namepos = pos % B.seg_size[win.seg];
+        const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
+        const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
+        // header text: @popu#chr#pos%segsize#fragCount[/m]\n  (Segment.cpp:780,809,824), written straight to
+        // HBM by the owner lane (~27 bytes per record; the kernel is nowhere near the HBM limit)
+        if (!(B.diag & 4u)) {
+          uint8_t* hp = B.out[m] + ooff;
+          for (uint32_t i = 0; i < B.prefix_len; i++) hp[i] = B.prefix[i];
+          hp += B.prefix_len;
+          const uint32_t nd1 = ndigits(namepos), nd2 = ndigits(fragcount);
+          uint32_t v = namepos;
+          for (uint32_t k = nd1; k-- > 0;) { const uint32_t qd = v / 10u; hp[k] = (uint8_t)('0' + (v - qd * 10u)); v = qd; }
+          hp[nd1] = '#';
+          hp += nd1 + 1u;
+          v = fragcount;
+          for (uint32_t k = nd2; k-- > 0;) { const uint32_t qd = v / 10u; hp[k] = (uint8_t)('0' + (v - qd * 10u)); v = qd; }
+          hp += nd2;
+          if (B.paired) { hp[0] = '/'; hp[1] = (uint8_t)('1' + m); hp += 2; }
+          hp[0] = '\n';
+        }
+        items = (np + 10u) / 8u;  // ceil((np + 3) / 8): bases + "\n+\n"
+        my0 = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), (uint32_t)ooff, (uint32_t)(ooff >> 32));
+        // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
+        // (sg_load_profile rejects profiles that could violate the bound)
+        my1 = make_uint4(flen | ((uint32_t)rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, 0u);
+      }
+    }
+    meta_rows[lane * 2] = my0;
+    meta_rows[lane * 2 + 1] = my1;
+    wave_lds_sync();
+
+    // ================= phase 1: lane = 8 consecutive bases, fixed lane -> (read, item) map =================
+    if (!(B.diag & 64u)) {
+      // main steps: RPI reads per step through the fixed map; then the reads grown by insertions past
+      // the TI items of the map (rare) finish one read at a time.  One call site keeps the loop small.
+      const uint32_t nmain = (G + RPI - 1u) / RPI;
+      unsigned long long more = __ballot(items > TI);
+      uint32_t cb = TI;
+      for (uint32_t step = 0;; step++) {
+        uint32_t r, c;
+        bool ok;
+        if (step < nmain) {
+          r = step * RPI + sub;
+          c = c_lane;
+          ok = lane_ok && r < G;
+          if (!ok) r = step * RPI;
+        } else {
+          if (!more) break;
+          r = (uint32_t)__builtin_ctzll(more);
+          c = cb + lane;
+          ok = true;
+        }
+        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+        const uint32_t np = m1.y & 0xFFFFu;
+        const uint32_t nitems = (np + 10u) / 8u;
+        if (step >= nmain) {
+          cb += 64u;
+          if (cb >= nitems) { more &= more - 1ull; cb = TI; }
+        }
+        const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+        emit_item<KT, QLG, SUB_LDS, QUAL_LDS>(P, B, lds_sub, lds_qual, gsub, m, m0, m1, g * G + r, active ? c : 0u, active);
+      }
+    }
+
+    wave_lds_sync();  // the next group's phase 0 rewrites the metadata rows
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// haplotype encoding: ASCII -> base code, in place (A0 C1 T2 G3, 'N' = 4, anything else = 5)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t encode4(uint32_t w) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t b = (w >> (8 * i)) & 0xFFu;
+    const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
+    const uint32_t v = acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : 5u);
+    o |= v << (8 * i);
+  }
+  return o;
+}
+__global__ __launch_bounds__(256) void encode_kernel(uint4* __restrict__ buf, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    uint4 v = buf[i];
+    v.x = encode4(v.x); v.y = encode4(v.y); v.z = encode4(v.z); v.w = encode4(v.w);
+    buf[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -461,9 +645,9 @@ __global__ __launch_bounds__(256) void gc_kernel(const uint8_t* __restrict__ cha
       uint32_t x = v[i];
       const int left = (int)rem - 4 * i;
       if (left <= 0) x = 0;
-      else if (left < 4) x &= (1u << (8 * left)) - 1u;
-      gc += count_eq_bytes(x, 'G') + count_eq_bytes(x, 'C');
-      nn += count_eq_bytes(x, 'N');
+      else if (left < 4) x &= (1u << (8 * left)) - 1u;  // masked-off bytes read as 0 = 'A': neither GC nor N
+      gc += count_eq_bytes(x, 1u) + count_eq_bytes(x, 3u);  // encoded C, G
+      nn += count_eq_bytes(x, 4u);                           // encoded N
     }
   }
 #pragma unroll
@@ -500,10 +684,51 @@ void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s) {
   hipLaunchKernelGGL(scan_sums_kernel, dim3(nm), dim3(1024), 0, s, bsum, nblk, B.totals);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk, nm), dim3(SCAN_BLOCK), 0, s, B.reclen, B.n_slots, bsum, nblk, B.recoff);
 }
+// LDS budget of emit_kernel: tables that fit are staged, the rest is read through L2.
+static const size_t kLdsBytes = 160 * 1024;
+template <int KT, int QLG, bool SL, bool QL>
+static void launch_emit_variant(const DevProfile& P, const DevBatch& B, dim3 grid, size_t lds, uint32_t sub_rows,
+                                uint32_t qual_words, uint32_t TI, uint32_t RPI, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)emit_kernel<KT, QLG, SL, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((emit_kernel<KT, QLG, SL, QL>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
+}
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
-  dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
-  hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, s, P, B);
+  uint32_t kmer_count = 0;
+  for (int m = 1, p = 1; m <= P.kmer; m++) { p *= 4; kmer_count += p; }
+  const uint32_t sub_rows = kmer_count * (uint32_t)P.bins;
+  const uint32_t qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW;
+  const size_t sub_b = (size_t)sub_rows * 16, qual_b = ((size_t)qual_words * 4 + 15) & ~(size_t)15;
+  const bool sub_lds = fixed + sub_b <= kLdsBytes;
+  const bool qual_lds = sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
+  const size_t lds = fixed + (sub_lds ? sub_b : 0) + (qual_lds ? qual_b : 0);
+  // fixed lane map: TI items of 8 bases per read, RPI reads per wave iteration
+  uint32_t TI = ((uint32_t)P.L + 3u + 7u) / 8u;
+  if (TI > 64u) TI = 64u;  // longer reads finish in the clean-up loop
+  const uint32_t RPI = 64u / TI;
+  const uint32_t G = RPI * (64u / RPI);
+  const uint32_t ngroups = (B.n_slots + G - 1u) / G;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const uint32_t nm = B.paired ? 2 : 1;
+  uint32_t gx = (uint32_t)cus / nm;  // one 1024-thread workgroup per CU, persistent over read groups
+  if (gx < 1) gx = 1;
+  const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
+  if (gx > need) gx = need;
+  dim3 grid(gx, nm);
+  const bool fast = P.kmer == 3 && P.qual_lg == 3;
+  if (fast && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  else launch_emit_variant<0, 0, false, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+}
+void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s) {  // bytes is a multiple of 16
+  if (!bytes) return;
+  const size_t n16 = bytes / 16;
+  uint32_t grid = (uint32_t)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(256), 0, s, (uint4*)buf, n16);
 }
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s) {
   if (!n) return;

@@ -54,6 +54,17 @@ Row encode_row(const double* cdf, int ac) {
   return r;
 }
 
+CompactRow encode_compact_row(const double* cdf, int ac) {
+  CompactRow r;
+  Row full = encode_row(cdf, ac);
+  for (size_t i = 0; i < full.T.size(); i++) {
+    if (i > 0 && full.T[i] == full.T[i - 1]) continue;  // zero mass: never the first hit
+    r.T.push_back(full.T[i]);
+    r.sym.push_back((uint8_t)(full.k0 + i));
+  }
+  return r;
+}
+
 void encode_sub_row(const double* cdf4, uint32_t out[4]) {
   uint64_t cnt[4];
   int k0 = -1;

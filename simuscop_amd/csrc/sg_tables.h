@@ -29,6 +29,15 @@ struct Row {
 };
 Row encode_row(const double* cdf, int ac);
 
+// Compact row: entries that can never be chosen (zero probability mass, i.e. the same count as their
+// predecessor) are dropped -- if x <= T[k] == T[k-1] then k-1 is found first -- and every kept entry
+// remembers which original index it stands for:  k = sym[#{i : x > T[i]}].  Exact for all 2^32 draws.
+struct CompactRow {
+  std::vector<uint32_t> T;    // strictly increasing, T.back() == 0xFFFFFFFF
+  std::vector<uint8_t> sym;   // original index of each kept entry
+};
+CompactRow encode_compact_row(const double* cdf, int ac);
+
 // Substitution row (N = 4): {T0, T1, T2, k0};  k = max(k0, (x>T0)+(x>T1)+(x>T2)).
 void encode_sub_row(const double* cdf4, uint32_t out[4]);
 
