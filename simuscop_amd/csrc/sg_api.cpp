@@ -20,6 +20,7 @@ void launch_namebase(const DevBatch& B, hipStream_t s);
 void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
+void launch_header(const DevBatch& B, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
@@ -58,7 +59,7 @@ struct sg_ctx {
   sg::DevProfile P{};
   sg::DevBatch B{};
   DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
-      recoff, totals, bsum, out1, out2, gcw, gco;
+      recoff, meta, totals, bsum, out1, out2, gcw, gco;
   uint64_t host_totals[4] = {0, 0, 0, 0};
   bool results_valid = false;
 
@@ -120,7 +121,7 @@ void sg_destroy(sg_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
-                    &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco})
+                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco})
     b->release();
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
@@ -361,6 +362,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
   SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
+  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 32);
   SG_ENSURE(ctx->totals, 4 * 8);
   SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
 
@@ -386,6 +388,8 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   B.paired = b->paired ? 1 : 0;
   B.prefix = ctx->prefix.as<uint8_t>();
   B.prefix_len = (uint32_t)plen;
+  for (int i = 0; i < 4; i++) B.prefix_w[i] = 0;
+  for (size_t i = 0; i < plen && i < 16; i++) B.prefix_w[i / 4] |= (uint32_t)(uint8_t)b->name_prefix[i] << (8 * (i % 4));
   B.pairs = ctx->pairs.as<sg::PairRec>();
   B.win_actual = ctx->win_actual.as<uint32_t>();
   B.win_namebase = ctx->win_namebase.as<uint32_t>();
@@ -393,6 +397,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   B.events = ctx->events.as<uint32_t>();
   B.reclen = ctx->reclen.as<uint32_t>();
   B.recoff = ctx->recoff.as<uint64_t>();
+  B.meta = ctx->meta.as<uint4>();
   B.totals = ctx->totals.as<uint64_t>();
   ctx->have_plan = true;
   ctx->sampled = false;
@@ -430,6 +435,7 @@ static int run_pass(sg_ctx* ctx) {
   B.out[1] = ctx->out2.as<uint8_t>();
   B.out_cap[0] = ctx->out1.cap;
   B.out_cap[1] = ctx->out2.cap;
+  sg::launch_header(B, s);
   sg::launch_emit(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));
   SG_HIP(hipGetLastError());

@@ -53,6 +53,7 @@ struct DevBatch {
   int32_t paired;
   const uint8_t* prefix;        // "@popu#chr#"
   uint32_t prefix_len;
+  uint32_t prefix_w[4];         // first 16 prefix bytes by value (longer prefixes fall back to the global copy)
   uint32_t k0, k1;              // philox key
   uint32_t diag;                // SG_DIAG timing ablations (0 in production; outputs are wrong otherwise)
   // work buffers
@@ -63,6 +64,7 @@ struct DevBatch {
   uint32_t* events;             // [2][n_slots][SG_MAX_EVENTS]
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
+  uint4* meta;                  // [2][n_slots][2] per-read rows for the emit kernel (see indel_kernel / header_kernel)
   uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] error flags
   uint8_t* out[2];
   uint64_t out_cap[2];

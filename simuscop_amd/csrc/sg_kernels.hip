@@ -149,10 +149,15 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   const size_t idx = (size_t)m * B.n_slots + t;
   const PairRec rec = B.pairs[t];
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
-  if (!flen) { B.rlen[idx] = 0; B.reclen[idx] = 0; return; }
+  if (!flen) {
+    B.rlen[idx] = 0; B.reclen[idx] = 0;
+    B.meta[idx * 2] = make_uint4(0, 0, 0, 0);
+    B.meta[idx * 2 + 1] = make_uint4(0, 0, 0, 0);
+    return;
+  }
   const int L = P.L;
   int j = 0, dl = 0;
-  uint32_t nev = 0;
+  uint32_t nev = 0, first_ev = 0;
   uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
   const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
   for (int c = 0; 2 * c < L; c++) {
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
         uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
           if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, len, 0);
+          if (nev == 0) first_ev = ev_pack((uint32_t)jj, len, 0);
           nev++;
           dl += (int)len;
         }
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
         if (len > 0) {
           uint32_t k = min((uint32_t)(L - jj), len);
           if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, k, 1);
+          if (nev == 0) first_ev = ev_pack((uint32_t)jj, k, 1);
           nev++;
           dl -= (int)k;
           j = jj + (int)k;
@@ -188,9 +195,72 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   const uint32_t np = (uint32_t)(L + dl);
   B.rlen[idx] = np | (nev << 16);
   const sg_window win = B.windows[rec.win];
-  const uint32_t namepos = (win.spos + rec.relpos) % B.seg_size[win.seg];
+  const uint32_t pos = win.spos + rec.relpos;
+  const uint32_t namepos = pos % B.seg_size[win.seg];
   const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-  B.reclen[idx] = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u + 2u * np + 4u;
+  const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
+  B.reclen[idx] = hdr + 2u * np + 4u;
+  // Per-read row for the emit kernel.  m0.z/.w carry the name fields until header_kernel has written
+  // the header text and replaces them by the record's byte offset.
+  const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
+  const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
+  B.meta[idx * 2] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
+  // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
+  // (sg_load_profile rejects profiles that could violate the bound)
+  // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
+  B.meta[idx * 2 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// header: one lane per read, after the offset scan.  Writes "@popu#chr#pos%segsize#fragCount[/m]\n"
+// (Segment.cpp:780,809,824) straight to HBM (~27 bytes per record) and completes the read's row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void header_kernel(DevBatch B) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = blockIdx.y;
+  if (t >= B.n_slots) return;
+  const size_t idx = (size_t)m * B.n_slots + t;
+  uint4 m0 = B.meta[idx * 2];
+  const uint4 m1 = B.meta[idx * 2 + 1];
+  if (!(m1.x & 0x7FFFFFFFu)) return;
+  const uint64_t ooff = B.recoff[idx];
+  if (ooff + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
+  const uint32_t namepos = m0.z, fragcount = m0.w;
+  if (!(B.diag & 4u)) {
+    // byte stream -> unaligned dword stores (7 instead of 27 byte stores per record)
+    uint8_t* hp = B.out[m] + ooff;
+    uint32_t w = 0, nb = 0;
+    auto push = [&](uint32_t b) {
+      w |= b << (nb * 8u);
+      if (++nb == 4u) { __builtin_memcpy(hp, &w, 4); hp += 4; w = 0; nb = 0; }
+    };
+    auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
+      const uint32_t nd = ndigits(v);
+      uint64_t lo = 0;  // last (up to 8) digits, most significant in byte 0
+      uint32_t hi = 0;  // leading digits of 9- and 10-digit numbers
+      for (uint32_t k = 0; k < nd; k++) {
+        const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
+        if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
+        v = qd;
+      }
+      for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
+      for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
+    };
+    if (B.prefix_len <= 16u) {
+      for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);
+    } else {
+      for (uint32_t i = 0; i < B.prefix_len; i++) push(B.prefix[i]);
+    }
+    push_dec(namepos);
+    push('#');
+    push_dec(fragcount);
+    if (B.paired) { push('/'); push('1' + m); }
+    push('\n');
+    for (uint32_t i = 0; i < nb; i++) hp[i] = (uint8_t)(w >> (8u * i));
+  }
+  m0.z = (uint32_t)ooff;
+  m0.w = (uint32_t)(ooff >> 32);
+  B.meta[idx * 2] = m0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,7 +361,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 // (Segment.cpp:803-832).
 //
 // Mapping (v3).  A wave owns G consecutive reads of one mate (one contiguous ~21 KB output range).
-//   phase 0  lane = read: gather its metadata into a 32-byte LDS row and write the record's header text.
+//   phase 0  lane = read: its 32-byte metadata row (written by indel_kernel / header_kernel) into LDS.
 //   phase 1  lane = 8 consecutive bases.  The lane -> (read-in-iteration, item) map is FIXED:
 //            TI = ceil((L+3)/8) items per read, RPI = 64/TI reads per wave iteration, so there is no
 //            search, no division and no shuffle in the loop; read metadata comes from two LDS b128
@@ -383,28 +453,70 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   const uint32_t revmask = rev ? 2u : 0u;  // complement in code space: A0<->T2, C1<->G3 (Segment.cpp:81-103)
 
   // ---- source codes for positions i0-5 .. i0+7 (index q = p - i0 + 5); >= 4 means "not in bases" ----
+  // Every lane loads the un-shifted template window: 16 encoded haplotype bytes; after the conditional
+  // byte reversal position p sits at byte p-i0+5.  Unused slots (flen == 0: last partial group,
+  // abandoned windows) read a harmless in-bounds address.
   uint32_t code[13];
-  if (nev == 0) {
-    // 16 encoded haplotype bytes; after the conditional byte reversal position p sits at byte p-i0+5
-    // unused slots (flen == 0: last partial group, abandoned windows) read a harmless in-bounds address
-    const uint8_t* src = flen == 0u ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
-    uint32_t w[4] = {0x00010203u + i0, 0x03020100u, 0x01000302u, 0x02030001u};
-    if (!(B.diag & 2u)) __builtin_memcpy(w, src, 16);
+  const uint8_t* src = flen == 0u ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
+  auto load_window = [&](const uint8_t* p16, uint32_t (&w)[4]) {
+    __builtin_memcpy(w, p16, 16);
     if (rev) {
       const uint32_t t0 = __builtin_bswap32(w[3]), t1 = __builtin_bswap32(w[2]);
       const uint32_t t2 = __builtin_bswap32(w[1]), t3 = __builtin_bswap32(w[0]);
       w[0] = t0; w[1] = t1; w[2] = t2; w[3] = t3;
     }
+  };
+  {
+    uint32_t w[4] = {0x00010203u + i0, 0x03020100u, 0x01000302u, 0x02030001u};
+    if (!(B.diag & 2u)) load_window(src, w);
 #pragma unroll
     for (int q = 0; q < 13; q++) code[q] = ((w[q >> 2] >> ((q & 3) * 8)) & 0xFFu) ^ revmask;
-  } else {
-    const uint32_t* ev = B.events + ((size_t)m * B.n_slots + slot) * SG_MAX_EVENTS;
-    const uint64_t packed = slow_codes(frag, flen, rev ? 1u : 0u, ev, nev, np, i0, K, slot + B.slot_offset,
-                                       dev_ctx(KIND_AUX, m, B.batch_id), B.k0, B.k1);
+  }
+  // Reads with exactly one sequencing indel (most event reads): past the event the template window is
+  // the same window shifted by +-len; inserted bases are redrawn from their addressed Philox stream.
+  if (__ballot(nev == 1u) != 0ull) {
+    if (nev == 1u) {
+      const uint32_t ew = m1.w;
+      const int ej = (int)(ew & 0xFFFFu), elen = (int)((ew >> 16) & 0x7FFFu);
+      const bool del = (ew >> 31) != 0;
+      const int delta = del ? elen : -elen;  // template index shift past the event
+      uint32_t w2[4];
+      load_window(rev ? src - delta : src + delta, w2);
+      const int first_shifted = del ? ej : ej + elen + 1;  // first output position that reads the shifted window
 #pragma unroll
-    for (int q = 0; q < 13; q++) {
-      const uint32_t v = (uint32_t)(packed >> (4 * q)) & 0xFu;
-      code[q] = (v & 8u) ? (0x100u | (v & 3u)) : v;
+      for (int q = 0; q < 13; q++) {
+        const int p = (int)i0 - 5 + q;
+        const uint32_t c2 = ((w2[q >> 2] >> ((q & 3) * 8)) & 0xFFu) ^ revmask;
+        if (p >= first_shifted) code[q] = c2;
+      }
+      if (!del) {
+        // inserted run occupies output positions ej+1 .. ej+elen: randomInteger(0, N-1), never the last
+        // base (Profile.cpp:1564); flat draw f = p - ej of stream (slot, ej)
+#pragma unroll 1
+        for (int q = 0; q < 13; q++) {
+          const int p = (int)i0 - 5 + q;
+          const bool ins = p > ej && p <= ej + elen && p >= 0;
+          if (__ballot(ins) == 0ull) continue;
+          if (ins) {
+            const uint32_t v = 0x100u | __umulhi(aux_draw(B, slot, (uint32_t)ej, (uint32_t)(p - ej), m), 3u);
+            // q is a loop variable: select through a mask instead of indexing registers dynamically
+#pragma unroll
+            for (int z = 0; z < 13; z++) if (z == q) code[z] = v;
+          }
+        }
+      }
+    }
+  }
+  if (__ballot(nev >= 2u) != 0ull) {
+    if (nev >= 2u) {
+      const uint32_t* ev = B.events + ((size_t)m * B.n_slots + slot) * SG_MAX_EVENTS;
+      const uint64_t packed = slow_codes(frag, flen, rev ? 1u : 0u, ev, nev, np, i0, K, slot + B.slot_offset,
+                                         dev_ctx(KIND_AUX, m, B.batch_id), B.k0, B.k1);
+#pragma unroll
+      for (int q = 0; q < 13; q++) {
+        const uint32_t v = (uint32_t)(packed >> (4 * q)) & 0xFu;
+        code[q] = (v & 8u) ? (0x100u | (v & 3u)) : v;
+      }
     }
   }
   // natural index (A0 C1 T2 G3) -> profile base code; inserted bases (0x100 flag) already are profile codes
@@ -512,48 +624,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
   const bool lane_ok = sub < RPI;
 
   for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
-    // ================= phase 0: lane = read =================
+    // ================= phase 0: lane = read: its 32-byte row (coalesced) into LDS =================
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
     if (lane < G && t < B.n_slots) {
-      const PairRec rec = B.pairs[t];
-      const uint32_t flen = rec.fl & 0x7FFFFFFFu;
-      if (flen) {
-        const size_t idx = (size_t)m * B.n_slots + t;
-        const uint32_t rl = B.rlen[idx];
-        const uint32_t np = rl & 0xFFFFu, nev = rl >> 16;
-        const sg_window win = B.windows[rec.win];
-        const uint32_t pos = win.spos + rec.relpos;
-        const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
-        const bool rev = B.paired ? (m == 1) : ((rec.fl >> 31) != 0);
-        const uint64_t ooff = B.recoff[idx];
-        const uint32_t namepos = pos % B.seg_size[win.seg];
-        const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-        const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
-        // header text: @popu#chr#pos%segsize#fragCount[/m]\n  (Segment.cpp:780,809,824), written straight to
-        // HBM by the owner lane (~27 bytes per record; the kernel is nowhere near the HBM limit)
-        if (!(B.diag & 4u)) {
-          uint8_t* hp = B.out[m] + ooff;
-          for (uint32_t i = 0; i < B.prefix_len; i++) hp[i] = B.prefix[i];
-          hp += B.prefix_len;
-          const uint32_t nd1 = ndigits(namepos), nd2 = ndigits(fragcount);
-          uint32_t v = namepos;
-          for (uint32_t k = nd1; k-- > 0;) { const uint32_t qd = v / 10u; hp[k] = (uint8_t)('0' + (v - qd * 10u)); v = qd; }
-          hp[nd1] = '#';
-          hp += nd1 + 1u;
-          v = fragcount;
-          for (uint32_t k = nd2; k-- > 0;) { const uint32_t qd = v / 10u; hp[k] = (uint8_t)('0' + (v - qd * 10u)); v = qd; }
-          hp += nd2;
-          if (B.paired) { hp[0] = '/'; hp[1] = (uint8_t)('1' + m); hp += 2; }
-          hp[0] = '\n';
-        }
-        items = (np + 10u) / 8u;  // ceil((np + 3) / 8): bases + "\n+\n"
-        my0 = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), (uint32_t)ooff, (uint32_t)(ooff >> 32));
-        // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
-        // (sg_load_profile rejects profiles that could violate the bound)
-        my1 = make_uint4(flen | ((uint32_t)rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, 0u);
-      }
+      const size_t idx = (size_t)m * B.n_slots + t;
+      my0 = B.meta[idx * 2];
+      my1 = B.meta[idx * 2 + 1];
+      if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;  // ceil((np + 3) / 8): bases + "\n+\n"
     }
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
@@ -674,6 +753,11 @@ void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
   dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
   hipLaunchKernelGGL(indel_kernel, grid, dim3(256), 0, s, P, B);
+}
+void launch_header(const DevBatch& B, hipStream_t s) {
+  if (!B.n_slots) return;
+  dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
+  hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B);
 }
 uint32_t scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s) {
