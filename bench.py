@@ -122,25 +122,9 @@ def main():
     L = 151
     # ---- read-count balancing (Genome::setReadCounts) ----
     my_wl = sess.weighted_length()
-    my_target = args.contig_len
-    if world > 1:
-        t = torch.tensor([my_wl, float(my_target)], dtype=torch.float64, device="cuda")
-        allv = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allv, t)           # RCCL over xGMI: 16 bytes per rank
-        wls = [float(v[0]) for v in allv]
-        total_len = int(sum(float(v[1]) for v in allv))
-    else:
-        wls, total_len = [my_wl], my_target
-    reads = total_len * args.coverage // L           # Genome.cpp:831
-    WL = 0.0
-    for w in wls:
-        WL += w
-    cur, my_reads = 0, 0
-    for i, w in enumerate(wls):                      # Genome.cpp:806-811
-        chr_reads = int(reads * (w / WL)) if i < len(wls) - 1 else reads - cur
-        if i == rank:
-            my_reads = chr_reads
-        cur += chr_reads
+    from simuscop_amd import dist as sdist
+    # all_gather of one fp64 pair per rank (RCCL over xGMI), then the reference's apportioning formula
+    my_reads, _ = sdist.balance_reads(my_wl, args.contig_len, args.coverage, L, device="cuda")
     sess.set_reads(my_reads)
     assert sess.prepare_batch(0)
     stream = torch.cuda.current_stream()

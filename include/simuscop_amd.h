@@ -126,6 +126,12 @@ int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_f
 /* Copy the FASTQ text to host buffers (the bytes SeqWriter::write(char*,char*) would receive,
  * lib/seqwriter/SeqWriter.cpp:41-54).  host_r2 may be NULL for SE.                               */
 int sg_fetch(sg_ctx* ctx, char* host_r1, char* host_r2);
+/* Partial copy for pipelined sinks: bytes [offset, offset+bytes) of mate 0/1's FASTQ text.  With a
+ * destination from sg_host_alloc (pinned) the copy runs at PCIe speed.                            */
+int sg_fetch_range(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, char* host_dst);
+/* Page-locked host memory for sg_fetch / sg_fetch_range destinations.                             */
+int sg_host_alloc(sg_ctx* ctx, uint64_t bytes, void** host_ptr);
+int sg_host_free(sg_ctx* ctx, void* host_ptr);
 /* Device pointers of the FASTQ text (valid until the next sg_sample / sg_plan).                  */
 int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2);
 

@@ -22,7 +22,8 @@ SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit"]
 ENGINE_SYMBOLS = [
     "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
     "sg_upload_haplotypes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
-    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_cdf_count_le",
+    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
+    "sg_host_free",
 ]
 
 
@@ -94,6 +95,9 @@ def load_engine():
     lib.sg_sample.argtypes = [vp]
     lib.sg_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.sg_fetch.argtypes = [vp, vp, vp]
+    lib.sg_fetch_range.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, vp]
+    lib.sg_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    lib.sg_host_free.argtypes = [vp, vp]
     lib.sg_device_output.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.sg_gc_percent.argtypes = [vp, C.POINTER(SgGcWindow), C.c_uint64, C.POINTER(C.c_int32)]
     lib.sg_set_profiling.argtypes = [vp, C.c_int]

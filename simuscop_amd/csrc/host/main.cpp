@@ -1,6 +1,6 @@
 // host/main.cpp -- `simuReads <configuration file>` (src/simuReads.cpp:24-97), GPU-backed.
 // Same positional argument, usage text and exit codes; optional flags are additive:
-//   --seed N  --device D  --out DIR  --no-write  --quiet  --rank R --world W  --stats
+//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +36,7 @@ int main(int argc, char* argv[]) {
     else if (a == "--device") opt.device = atoi(val());
     else if (a == "--out") { out = val(); opt.output_dir = out.c_str(); }
     else if (a == "--no-write") opt.write_files = 0;
+    else if (a == "--fetch") opt.fetch = 1;
     else if (a == "--quiet") opt.quiet = 1;
     else if (a == "--rank") opt.shard_rank = atoi(val());
     else if (a == "--world") opt.shard_world = atoi(val());

@@ -12,6 +12,9 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +80,10 @@ struct Driver {
   std::vector<sg_gc_window> gcw;
   std::vector<int32_t> gcv;
 
+  ~Driver() {
+    for (void* b : pinned)
+      if (b && eng.ctx) sg_host_free(eng.ctx, b);
+  }
   void log(const std::string& s) { if (!opt.quiet) std::cerr << s; }
 
   void upload(const std::string& popu, const std::string& chr) {
@@ -276,19 +283,67 @@ struct Driver {
     st.fragments += nf;
     st.reads += paired ? 2 * nf : nf;
     st.fastq_bytes += n1 + n2;
-    if (opt.write_files || opt.fetch) {
-      t0 = Clock::now();
-      if (host1.size() < n1) host1.resize(n1);
-      if (host2.size() < n2) host2.resize(n2);
-      eng.check(sg_fetch(eng.ctx, host1.data(), paired ? host2.data() : nullptr), "sg_fetch");
-      st.t_fetch += since(t0);
-      if (opt.write_files) {
-        t0 = Clock::now();
-        if (n1 && fwrite(host1.data(), 1, n1, sink.f1) != n1) throw Error("Error: short write to fastq file", -1);
-        if (paired && n2 && fwrite(host2.data(), 1, n2, sink.f2) != n2) throw Error("Error: short write to fastq file", -1);
-        st.t_write += since(t0);
+    if (opt.write_files || opt.fetch) drain(n1, n2, sink);
+  }
+
+  // FASTQ sink (the reference's SeqWriter::write, lib/seqwriter/SeqWriter.cpp:41-54): D2H in pinned
+  // 64 MB chunks, double buffered, while a writer thread appends the previous chunk to the files.
+  // Mate 1 and mate 2 text are independent byte streams into their own files, so pair order is kept.
+  static constexpr size_t kChunk = 64u << 20;
+  void* pinned[2] = {nullptr, nullptr};
+  void drain(uint64_t n1, uint64_t n2, Sink& sink) {
+    for (void*& b : pinned)
+      if (!b) eng.check(sg_host_alloc(eng.ctx, kChunk, &b), "sg_host_alloc");
+    struct Job { FILE* f; const char* p; size_t n; };
+    std::mutex mu;
+    std::condition_variable cv;
+    Job job{nullptr, nullptr, 0};
+    bool have = false, stop = false, failed = false;
+    double t_write = 0;
+    std::thread writer([&]() {
+      for (;;) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return have || stop; });
+        if (!have && stop) return;
+        Job j = job;
+        lk.unlock();
+        auto tw = Clock::now();
+        if (j.f && j.n && fwrite(j.p, 1, j.n, j.f) != j.n) failed = true;
+        t_write += since(tw);
+        lk.lock();
+        have = false;
+        cv.notify_all();
+      }
+    });
+    auto t0 = Clock::now();
+    int cur = 0;
+    const bool paired = cfg.paired();
+    for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+      const uint64_t total = mate ? n2 : n1;
+      FILE* f = opt.write_files ? (mate ? sink.f2 : sink.f1) : nullptr;
+      for (uint64_t off = 0; off < total; off += kChunk) {
+        const size_t n = (size_t)std::min<uint64_t>(kChunk, total - off);
+        int rc = sg_fetch_range(eng.ctx, mate, off, n, (char*)pinned[cur]);  // overlaps the writer's fwrite
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !have; });  // the other buffer is free again
+        if (rc != SG_OK) { stop = true; cv.notify_all(); lk.unlock(); writer.join(); eng.check(rc, "sg_fetch_range"); }
+        job = Job{f, (const char*)pinned[cur], n};
+        have = true;
+        cv.notify_all();
+        cur ^= 1;
       }
     }
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return !have; });
+      stop = true;
+      cv.notify_all();
+    }
+    writer.join();
+    const double wall = since(t0);
+    st.t_write += t_write;
+    st.t_fetch += wall > t_write ? wall - t_write : 0;  // fetch time not hidden behind the writer
+    if (failed) throw Error("Error: short write to fastq file", -1);
   }
 
   Clock::time_point t_all;

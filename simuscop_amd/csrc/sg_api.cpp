@@ -478,6 +478,32 @@ int sg_fetch(sg_ctx* ctx, char* host_r1, char* host_r2) {
   return SG_OK;
 }
 
+int sg_fetch_range(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, char* host_dst) {
+  if (!ctx || (bytes && !host_dst) || mate < 0 || mate > 1) return SG_ERR_INVALID;
+  if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: call sg_sample first");
+  if (mate == 1 && !ctx->B.paired) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: single-end batch has no mate 2");
+  if (offset + bytes > ctx->host_totals[mate]) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: range past the end of the FASTQ text");
+  if (!bytes) return SG_OK;
+  SG_HIP(hipSetDevice(ctx->device));
+  const char* src = (const char*)(mate ? ctx->out2.p : ctx->out1.p) + offset;
+  SG_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  return SG_OK;
+}
+
+int sg_host_alloc(sg_ctx* ctx, uint64_t bytes, void** host_ptr) {
+  if (!ctx || !host_ptr) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return SG_OK;
+}
+
+int sg_host_free(sg_ctx* ctx, void* host_ptr) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (host_ptr) SG_HIP(hipHostFree(host_ptr));
+  return SG_OK;
+}
+
 int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2) {
   if (!ctx) return SG_ERR_INVALID;
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_device_output: call sg_sample first");
