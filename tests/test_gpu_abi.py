@@ -1,0 +1,152 @@
+"""GPU tests that drive the C ABI directly (no CLI): GC scan against numpy, call-order / argument
+errors, and size-independent properties of a full-size pass (BASELINE C2: chr20-sized contig, XTen
+PE151, 30x, 6.4 M pairs): record structure, mate synchronisation, counts, determinism under the seed,
+and reads mapping back to the haplotype at the position their name carries."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import simuscop_amd
+from simuscop_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return simuscop_amd.load_engine()
+
+
+def _ctx(eng, seed=1):
+    ctx = C.c_void_p()
+    rc = eng.sg_create(C.byref(ctx), 0, seed)
+    assert rc == 0, eng.sg_last_error(None)
+    return ctx
+
+
+def test_gc_percent_matches_numpy(eng):
+    rng = np.random.default_rng(3)
+    n = 300000
+    chain = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    chain[5000:5400] = ord("N")
+    chain[70000] = ord("R")  # neither GC nor N (MyDefine.cpp:286-292)
+    chain2 = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1234, p=[0.1, 0.4, 0.4, 0.1])
+    ctx = _ctx(eng)
+    try:
+        bufs = [chain.tobytes(), chain2.tobytes()]
+        arr = (C.c_char_p * 2)(*bufs)
+        lens = (C.c_uint64 * 2)(len(bufs[0]), len(bufs[1]))
+        assert eng.sg_upload_haplotypes(ctx, 2, arr, lens) == 0
+        wins = []
+        for s in range(0, n - 1000, 997):
+            wins.append((s, 0, 1000))
+        wins += [(n - 333, 0, 333), (0, 1, 1234), (7, 1, 1), (100, 1, 17), (4990, 0, 11), (69990, 0, 20)]
+        w = (simuscop_amd.SgGcWindow * len(wins))(*[simuscop_amd.SgGcWindow(s, c, l) for s, c, l in wins])
+        out = (C.c_int32 * len(wins))()
+        assert eng.sg_gc_percent(ctx, w, len(wins), out) == 0, eng.sg_last_error(ctx)
+        for i, (s, c, l) in enumerate(wins):
+            seg = (chain if c == 0 else chain2)[s:s + l]
+            exp = -1 if (seg == ord("N")).any() else 100 * int(((seg == ord("G")) | (seg == ord("C"))).sum()) // l
+            assert out[i] == exp, (i, s, c, l, out[i], exp)
+        # a window past the chain end is refused on the host, not left to fault on the device
+        bad = (simuscop_amd.SgGcWindow * 1)(simuscop_amd.SgGcWindow(n - 10, 0, 100))
+        assert eng.sg_gc_percent(ctx, bad, 1, out) != 0
+    finally:
+        eng.sg_destroy(ctx)
+
+
+def test_call_order_and_argument_errors(eng):
+    ctx = _ctx(eng)
+    try:
+        b = simuscop_amd.SgBatch()
+        assert eng.sg_plan(ctx, C.byref(b)) != 0 and b"sg_load_profile" in eng.sg_last_error(ctx)
+        assert eng.sg_sample(ctx) != 0 and b"sg_plan" in eng.sg_last_error(ctx)
+        n1 = C.c_uint64()
+        assert eng.sg_result(ctx, C.byref(n1), None, None) != 0
+    finally:
+        eng.sg_destroy(ctx)
+    bad = C.c_void_p()
+    assert eng.sg_create(C.byref(bad), 9999, 1) != 0 and not bad.value
+
+
+@pytest.fixture(scope="module")
+def c2_session(tmp_path_factory):
+    wd = str(tmp_path_factory.mktemp("c2"))
+    fa = os.path.join(wd, "ref.fa")
+    L = 64444167
+    synth.write_fasta(fa, [("chr20", L)], seed=20)
+    cfg = os.path.join(wd, "config.txt")
+    with open(cfg, "w") as f:
+        f.write(f"ref = {fa}\nprofile = {os.path.join(cases.TESTDATA, cases.PROFILES['xten'])}\nname = sim\n"
+                f"output = {wd}/out\nlayout = PE\nthreads = 1\nverbose = 0\ncoverage = 30\ninsertSize = 350\n")
+    sess = simuscop_amd.Session(cfg, device=0, write_files=0, quiet=1, seed=12345)
+    sess.weighted_length()
+    sess.set_reads(sess.planned_reads)
+    assert sess.prepare_batch(0)
+    ref = synth.synth_contig(L, 20, 0)
+    ref = np.where((ref >= 97) & (ref <= 122), ref - 32, ref).astype(np.uint8)
+    yield sess, ref
+    sess.close()
+
+
+def _head(sess, nbytes=32 << 20):
+    sess.sample()
+    b1, b2, nf = sess.result()
+    buf1, buf2 = C.create_string_buffer(nbytes), C.create_string_buffer(nbytes)
+    assert sess.eng.sg_fetch_range(sess.ctx, 0, 0, nbytes, buf1) == 0
+    assert sess.eng.sg_fetch_range(sess.ctx, 1, 0, nbytes, buf2) == 0
+    return b1, b2, nf, buf1.raw, buf2.raw
+
+
+def test_full_size_pass_properties(c2_session):
+    sess, ref = c2_session
+    b1, b2, nf, r1, r2 = _head(sess)
+    planned = sess.planned_reads
+    # ceil(n/2) pairs per window (Segment.cpp:848): at least planned/2, at most one extra pair per window
+    assert planned // 2 <= nf <= planned // 2 + 200000
+    assert abs(b1 - b2) < 0.001 * b1 and 300 * nf < b1 < 340 * nf   # ~330 B per 151-bp record
+    qual_alphabet = set(b")-7<AFJ")
+    rec1 = r1[:r1.rfind(b"\n@") + 1].split(b"\n")
+    rec2 = r2[:r2.rfind(b"\n@") + 1].split(b"\n")
+    n = min(len(rec1), len(rec2)) // 4
+    assert n > 90000
+    mism = tot = 0
+    lens = {}
+    for i in range(0, n, 7):
+        h1, s1, p1, q1 = rec1[4 * i:4 * i + 4]
+        h2, s2, p2, q2 = rec2[4 * i:4 * i + 4]
+        assert h1.startswith(b"@sim#20#") and h1.endswith(b"/1") and h2 == h1[:-1] + b"2"   # mates stay in sync
+        assert p1 == b"+" and p2 == b"+" and len(s1) == len(q1) and len(s2) == len(q2)
+        assert set(s1) <= set(b"ACGTN") and set(s2) <= set(b"ACGTN")
+        for s_, q_ in ((s1, q1), (s2, q2)):   # called bases carry profile qualities; 'N' carries U{33..52} (Profile.cpp:1582)
+            assert all((q in qual_alphabet) if b != 78 else (33 <= q <= 52) for b, q in zip(s_, q_))
+        lens[len(s1)] = lens.get(len(s1), 0) + 1
+        if len(s1) == 151:
+            pos = int(h1.split(b"#")[2])          # single <=1 Mbp segments: pos % segsize, segment-relative
+            seg = i  # unknown segment: try all starts congruent mod 1e6 is costly; use the first segment only
+            if i < 20000:                          # first records belong to segment 0 (starts at 1)
+                r = ref[pos:pos + 151].tobytes()
+                if len(r) == 151 and b"N" not in r:
+                    d = sum(a != b for a, b in zip(s1, r))
+                    if d <= 20:
+                        mism += d
+                        tot += 151
+    assert 50 <= min(lens) and max(lens) < 151 + 8 * 46
+    assert lens.get(151, 0) > 0.75 * sum(lens.values())             # ~83 % of reads carry no sequencing indel
+    assert tot > 100 * 151 and mism / tot < 0.01                    # reads map back where their name says
+
+
+def test_pass_is_a_pure_function_of_the_seed(c2_session):
+    sess, _ = c2_session
+    sess.set_seed(777)
+    a = _head(sess, 8 << 20)
+    b = _head(sess, 8 << 20)
+    assert a[:3] == b[:3] and hashlib.md5(a[3]).digest() == hashlib.md5(b[3]).digest() and a[4] == b[4]
+    sess.set_seed(778)
+    c = _head(sess, 8 << 20)
+    assert c[2] == a[2]                      # the plan (counts) does not depend on the sampling seed ...
+    assert c[3] != a[3] and c[4] != a[4]     # ... the reads do
