@@ -210,7 +210,9 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     qr[r] = sg::encode_compact_row(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
     if (qr[r].T.size() > wmax) wmax = (uint32_t)qr[r].T.size();
   }
-  const uint32_t qW = sg::pow2_at_least(wmax), qstride = qW + qW / 4;
+  // odd row stride: consecutive rows start on different LDS banks (an even stride of 10 words put
+  // every first probe on 16 of the 32 banks: 62 % of LDS cycles were conflicts)
+  const uint32_t qW = sg::pow2_at_least(wmax), qstride = (qW + qW / 4) | 1u;
   const size_t qual_off = tab.size();
   tab.resize(qual_off + qrows * qstride, 0xFFFFFFFFu);
   for (size_t r = 0; r < qrows; r++) {
@@ -240,6 +242,29 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   add_row(pr->del_cdf, pr->n_del, del_off, del_lg);
   const bool has_isz = pr->isize_cdf != nullptr && pr->n_isize > 0;
   if (has_isz) add_row(pr->isize_cdf, pr->n_isize, isz_off, isz_lg);
+  // Fast-kernel context permutation.  The kernel packs base codes 2 bits each in NATURAL order
+  // (A0 C1 T2 G3) with the OLDEST base of a context in the lowest digit; the reference numbers a
+  // context with its oldest base in the highest digit, in `bases` order (Profile::initKmers).
+  const size_t perm_off = tab.size();
+  uint32_t inv_remap = 0;
+  for (int n = 0; n < 4; n++) inv_remap |= (uint32_t)n << (2 * ((remap >> (2 * n)) & 3u));
+  {
+    uint32_t off = 0, p4 = 1;
+    for (int m = 1; m <= pr->kmer; m++) {
+      p4 *= 4;
+      for (uint32_t v = 0; v < p4; v++) {
+        uint32_t src = 0;
+        for (int tt = 0; tt < m; tt++) {
+          const uint32_t nat = (v >> (2 * tt)) & 3u;            // base at age position tt (0 = oldest)
+          const uint32_t prof = (remap >> (2 * nat)) & 3u;
+          src |= prof << (2 * (m - 1 - tt));
+        }
+        tab.push_back(off + src);
+      }
+      off += p4;
+    }
+    while (tab.size() % 4) tab.push_back(0);
+  }
 
   SG_ENSURE(ctx->tab, tab.size() * 4);
   SG_HIP(hipMemcpyAsync(ctx->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -255,6 +280,8 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   P.ins_row = base + ins_off; P.ins_lg = ins_lg;
   P.del_row = base + del_off; P.del_lg = del_lg;
   P.isz_row = has_isz ? base + isz_off : nullptr; P.isz_lg = isz_lg;
+  P.sub_perm = base + perm_off;
+  P.inv_remap_packed = inv_remap;
   P.isz_min = pr->isize_min;
   P.fixed_isz = pr->insert_size;
   // getIndelSeq: `p <= insertRate`, then `p < delRate/(1-insertRate)` with p = x/2^32 (Profile.cpp:1560-1570)

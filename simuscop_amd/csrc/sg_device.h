@@ -36,6 +36,8 @@ struct DevProfile {
   uint32_t remap_packed;       // natural index (A0 C1 T2 G3) -> profile base code, 2 bits each
   uint32_t bases_packed;       // profile base code -> ASCII, 8 bits each
   uint32_t kmer_off[8];        // kmer_off[m] = first table index of contexts with m real bases
+  const uint32_t* sub_perm;    // fast kernel: context id in packed-natural digit order -> reference context id
+  uint32_t inv_remap_packed;   // profile base code -> natural index (A0 C1 T2 G3), 2 bits each
 };
 
 struct DevBatch {

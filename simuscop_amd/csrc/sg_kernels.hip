@@ -15,6 +15,7 @@
 //                    (Segment.cpp:803-832)
 //   gc_kernel        calculateGCPercent              (lib/mydefine/MyDefine.cpp:279-303)
 #include <algorithm>
+#include <cstdlib>
 
 #include "sg_device.h"
 
@@ -31,9 +32,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    c0 = hi1 ^ c1 ^ k0;
+    c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);  // three-input xor in one v_bitop3_b32
     c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
+    c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
@@ -676,6 +677,251 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
 }
 
 // ------------------------------------------------------------------------------------------------
+// emit, fast variant for the common profile shape: kmer == 3, quality rows of <= 8 symbols, both
+// tables in LDS.  Same mapping and results as emit_kernel, far fewer instructions:
+//   * the 13 source codes of an item are packed 2 bits each (natural order A0 C1 T2 G3) into one
+//     word, so a k-mer context is ONE bit-field extract; the LDS copy of the substitution table is
+//     permuted at staging time to that digit order (DevProfile::sub_perm), the quality rows to the
+//     natural reference-base order;
+//   * the 8-base block is straight-line and branch-free (the compiler can overlap the LDS reads of
+//     different bases); first-of-read contexts ("XXb", "Xbb") use per-lane extract constants, the
+//     record tail ("\n+\n", '\n') is patched on the packed 8-byte words;
+//   * windows holding a non-ACGT base and reads with >= 2 sequencing indels (both rare) fall back to
+//     the generic item code, out of line.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..3) -> 8 bits
+  return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
+}
+
+template <bool PAIRED>
+__device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
+                                          const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
+                                          uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
+                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1) {
+  const uint32_t bins = (uint32_t)P.bins;
+  const uint32_t flen = m1.x & 0x7FFFFFFFu;
+  const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
+  const uint32_t np = m1.y & 0xFFFFu, nev = (m1.y >> 16) & 0xFu, hdr = m1.y >> 20;
+  const uint32_t inv = m1.z;
+  const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
+  const uint32_t i0 = 8u * c;
+  const uint8_t* src = flen == 0u ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
+
+  // 16 encoded bytes -> byte order by position (reverse reads), complement, validity, 2-bit pack
+  auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
+    uint32_t w[4];
+    __builtin_memcpy(w, p16, 16);
+    if (rev) {  // PAIRED: wave-uniform branch
+      const uint32_t t0 = __builtin_bswap32(w[3]) ^ 0x02020202u, t1 = __builtin_bswap32(w[2]) ^ 0x02020202u;
+      const uint32_t t2 = __builtin_bswap32(w[1]) ^ 0x02020202u, t3 = __builtin_bswap32(w[0]) ^ 0x02020202u;
+      w[0] = t0; w[1] = t1; w[2] = t2; w[3] = t3;
+    }
+    // positions i0-2 .. i0+7 are bytes 3..12 (complementing an invalid code 4/5 gives 6/7: still >= 4)
+    bad = (w[0] & 0xFC000000u) | ((w[1] | w[2]) & 0xFCFCFCFCu) | (w[3] & 0xFCu);
+    return pack4(w[0]) | (pack4(w[1]) << 8) | (pack4(w[2]) << 16) | ((w[3] & 3u) << 24);
+  };
+  uint32_t bad;
+  uint32_t cw = window(src, bad);
+
+  // reads with exactly one sequencing indel: past the event the window is shifted by +-len
+  if (__ballot(nev == 1u) != 0ull) {
+    if (nev == 1u) {
+      const uint32_t ew = m1.w;
+      const int ej = (int)(ew & 0xFFFFu), elen = (int)((ew >> 16) & 0x7FFFu);
+      const bool del = (ew >> 31) != 0;
+      const int delta = del ? elen : -elen;
+      uint32_t bad2;
+      const uint32_t cw2 = window(rev ? src - delta : src + delta, bad2);
+      bad |= bad2;
+      const int first_shifted = del ? ej : ej + elen + 1;       // first output position reading the shifted window
+      const int q0 = first_shifted - ((int)i0 - 5);               // its index in the item window
+      const uint32_t keep = q0 <= 0 ? 0u : (q0 >= 13 ? 0xFFFFFFFFu : ((1u << (2 * q0)) - 1u));
+      cw = (cw & keep) | (cw2 & ~keep);
+      if (!del) {
+        // inserted run = output positions ej+1 .. ej+elen: randomInteger(0, N-1), never the last base
+        // (Profile.cpp:1564); flat draw f = p - ej of stream (slot, ej); codes are `bases` indexes
+#pragma unroll 1
+        for (int q = 3; q < 13; q++) {
+          const int p = (int)i0 - 5 + q;
+          const bool ins = p > ej && p <= ej + elen;
+          if (__ballot(ins) == 0ull) continue;
+          if (ins) {
+            const uint32_t prof = __umulhi(aux_draw(B, slot, (uint32_t)ej, (uint32_t)(p - ej), m), 3u);
+            const uint32_t nat = (P.inv_remap_packed >> (2u * prof)) & 3u;
+            cw = (cw & ~(3u << (2 * q))) | (nat << (2 * q));
+          }
+        }
+      }
+    }
+  }
+  const bool slow = active && (bad != 0u || nev >= 2u);  // queued for the generic item code by the caller
+  const bool go = active && !slow;
+
+  // ---- four Philox calls: [sub, qual] for 8 bases (counter = i/2) ----
+  uint32_t x[16];
+  const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+#pragma unroll
+  for (int h = 0; h < 4; h++) philox4x32_10(slot + B.slot_offset, 4u * c + (uint32_t)h, 0, c3b, B.k0, B.k1, x + 4 * h);
+
+  uint32_t sw[2] = {0, 0}, qw[2] = {0, 0};
+  const uint32_t ib0 = __umul24(i0, bins);
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    const uint32_t xs = x[2 * h], xq = x[2 * h + 1];
+    // context id in packed digit order; first two bases of a read use the short-context blocks
+    uint32_t kv;
+    if (h == 0) kv = __builtin_amdgcn_ubfe(cw, hoff0, hw0) + hk0;
+    else if (h == 1) kv = __builtin_amdgcn_ubfe(cw, hoff1, hw1) + hk1;
+    else kv = ((cw >> (2 * h + 6)) & 63u) + 20u;
+    const uint32_t bin = min(__umulhi(ib0 + (uint32_t)h * bins, inv), bins - 1u);  // i*binCount/n'
+    const uint4 row = lds_sub[__umul24(kv, bins) + bin];
+    const uint32_t k = max((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z), row.w);
+    const uint32_t cd = (cw >> (2 * h + 10)) & 3u;
+    const uint32_t* qrow = lds_qual + __umul24(__umul24((cd << 2) | k, bins) + bin, P.qual_stride);
+    uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
+    pos += (xq > qrow[pos + 1]) ? 2u : 0u;
+    pos += (xq > qrow[pos]) ? 1u : 0u;
+    const uint32_t sym = (qrow[8 + (pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+    const uint32_t ch = (P.bases_packed >> (8u * k)) & 0xFFu;
+    sw[h >> 2] |= ch << (8 * (h & 3));
+    qw[h >> 2] |= ((uint32_t)P.min_qual + sym) << (8 * (h & 3));
+  }
+  if (go) {
+    uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
+    uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
+    uint8_t* qo = so + np + 3u;
+    if (i0 + 8u <= np) {
+      __builtin_memcpy(so, &S, 8);
+      __builtin_memcpy(qo, &Q, 8);
+    } else {
+      // record tail: "\n+\n" after the bases, '\n' after the qualities
+      const int d = (int)np - (int)i0;  // bases in this item: -2 .. 7
+      if (d >= 0) {
+        const uint64_t keep = (1ull << (8 * d)) - 1ull;
+        S = (S & keep) | (0x0A2B0Aull << (8 * d));
+        Q = (Q & keep) | (0x0Aull << (8 * d));
+      } else {
+        S = 0x0A2B0Aull >> (8 * -d);
+      }
+      const uint32_t ns = min(8u, np + 3u - i0), nq = d >= 0 ? min(8u, (uint32_t)d + 1u) : 0u;
+      for (uint32_t b2 = 0; b2 < ns; b2++) so[b2] = (uint8_t)(S >> (8 * b2));
+      for (uint32_t b2 = 0; b2 < nq; b2++) qo[b2] = (uint8_t)(Q >> (8 * b2));
+    }
+  }
+  return slow;
+}
+
+#define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
+
+template <bool PAIRED>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
+                                                                 uint32_t TI, uint32_t RPI) {
+  extern __shared__ uint4 smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t m = blockIdx.y;
+  const uint32_t tm = PAIRED ? m : 0u;
+  const uint32_t bins = (uint32_t)P.bins;
+  uint4* lds_sub = smem;
+  uint32_t* lds_qual = (uint32_t*)(smem + sub_rows);
+  uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
+  uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
+  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
+  // staging with the fast kernel's digit / base-order permutations
+  for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
+    const uint32_t d = i / bins, b = i - d * bins;
+    lds_sub[i] = gsub[(size_t)P.sub_perm[d] * bins + b];
+  }
+  const uint32_t qrow_words = 4u * bins * P.qual_stride;  // rows of one reference base
+  for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {
+    const uint32_t cdn = i / qrow_words, rest = i - cdn * qrow_words;
+    lds_qual[i] = P.qual[((P.remap_packed >> (2u * cdn)) & 3u) * qrow_words + rest];
+  }
+  __syncthreads();
+  uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
+  uint32_t* slow_list = slow_all + wv * SLOW_CAP;
+
+  const uint32_t G = RPI * (64u / RPI);
+  const uint32_t ngroups = (B.n_slots + G - 1u) / G;
+  const uint32_t sub = lane / TI, c_lane = lane - sub * TI;
+  const bool lane_ok = sub < RPI;
+  // first item of a read: its first two bases have 1- and 2-base contexts ("XXb", "Xbb")
+  const bool head = c_lane == 0u;
+  const uint32_t hoff0 = head ? 10u : 6u, hw0 = head ? 2u : 6u, hk0 = head ? 0u : 20u;
+  const uint32_t hoff1 = head ? 10u : 8u, hw1 = head ? 4u : 6u, hk1 = head ? 4u : 20u;
+
+  for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
+    const uint32_t t = g * G + lane;
+    uint32_t items = 0;
+    uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
+    if (lane < G && t < B.n_slots) {
+      const size_t idx = (size_t)m * B.n_slots + t;
+      my0 = B.meta[idx * 2];
+      my1 = B.meta[idx * 2 + 1];
+      if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;
+    }
+    meta_rows[lane * 2] = my0;
+    meta_rows[lane * 2 + 1] = my1;
+    wave_lds_sync();
+    const uint32_t nmain = (G + RPI - 1u) / RPI;
+    unsigned long long more = __ballot(items > TI);
+    uint32_t cb = TI;
+    uint32_t nslow = 0;  // wave-uniform
+    auto flush_slow = [&]() {
+      wave_lds_sync();
+      for (uint32_t b0 = 0; b0 < nslow; b0 += 64u) {
+        const uint32_t i = b0 + lane;
+        const bool act = i < nslow;
+        const uint32_t e = slow_list[act ? i : 0u];
+        const uint32_t r = e & 0xFFu, c = e >> 8;
+        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+        emit_item<0, 0, false, false>(P, B, nullptr, nullptr, gsub, m, m0, m1, g * G + r, c, act);
+      }
+      nslow = 0;
+      wave_lds_sync();
+    };
+    for (uint32_t step = 0;; step++) {
+      // one call site for the (large, inlined) generic code: when the queue is nearly full or at the end
+      const bool done = step >= nmain && !more;
+      if (done || nslow > SLOW_CAP - 64u) {
+        flush_slow();
+        if (done) break;
+      }
+      uint32_t r, c;
+      bool ok;
+      uint32_t o0 = hoff0, a0 = hw0, k0_ = hk0, o1 = hoff1, a1 = hw1, k1_ = hk1;
+      if (step < nmain) {
+        r = step * RPI + sub;
+        c = c_lane;
+        ok = lane_ok && r < G;
+        if (!ok) r = step * RPI;
+      } else {
+        r = (uint32_t)__builtin_ctzll(more);
+        c = cb + lane;   // items past the fixed map are never the first item of a read
+        ok = true;
+        o0 = 6u; a0 = 6u; k0_ = 20u; o1 = 8u; a1 = 6u; k1_ = 20u;
+      }
+      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+      const uint32_t np = m1.y & 0xFFFFu;
+      const uint32_t nitems = (np + 10u) / 8u;
+      if (step >= nmain) {
+        cb += 64u;
+        if (cb >= nitems) { more &= more - 1ull; cb = TI; }
+      }
+      const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+      const bool slow = fast_item<PAIRED>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
+                                          active, o0, a0, k0_, o1, a1, k1_);
+      // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
+      const unsigned long long sm = __ballot(slow);
+      if (sm) {
+        if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
+        nslow += (uint32_t)__popcll(sm);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // haplotype encoding: ASCII -> base code, in place (A0 C1 T2 G3, 'N' = 4, anything else = 5)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t encode4(uint32_t w) {
@@ -782,7 +1028,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   for (int m = 1, p = 1; m <= P.kmer; m++) { p *= 4; kmer_count += p; }
   const uint32_t sub_rows = kmer_count * (uint32_t)P.bins;
   const uint32_t qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4;
   const size_t sub_b = (size_t)sub_rows * 16, qual_b = ((size_t)qual_words * 4 + 15) & ~(size_t)15;
   const bool sub_lds = fixed + sub_b <= kLdsBytes;
   const bool qual_lds = sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
@@ -802,8 +1048,16 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
   dim3 grid(gx, nm);
-  const bool fast = P.kmer == 3 && P.qual_lg == 3;
-  if (fast && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  const bool fast = P.kmer == 3 && P.qual_lg == 3 && sub_lds && qual_lds && getenv("SG_DIAG") == nullptr;
+  if (fast) {
+    if (B.paired) {
+      (void)hipFuncSetAttribute((const void*)emit_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((emit_fast_kernel<true>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
+    } else {
+      (void)hipFuncSetAttribute((const void*)emit_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((emit_fast_kernel<false>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
+    }
+  } else if (P.kmer == 3 && P.qual_lg == 3 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else launch_emit_variant<0, 0, false, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
