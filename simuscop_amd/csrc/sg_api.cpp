@@ -20,7 +20,7 @@ void launch_namebase(const DevBatch& B, hipStream_t s);
 void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
-void launch_header(const DevBatch& B, hipStream_t s);
+void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
@@ -284,6 +284,8 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   P.inv_remap_packed = inv_remap;
   P.isz_min = pr->isize_min;
   P.fixed_isz = pr->insert_size;
+  P.isz_lo = has_isz ? pr->isize_min : pr->insert_size;
+  P.isz_hi = has_isz ? pr->isize_min + pr->n_isize - 1 : pr->insert_size;
   // getIndelSeq: `p <= insertRate`, then `p < delRate/(1-insertRate)` with p = x/2^32 (Profile.cpp:1560-1570)
   uint64_t ci = sg::count_unit_le(pr->insert_rate);
   P.Tins = (uint32_t)(ci - 1);  // ci >= 1 for any rate >= 0
@@ -389,7 +391,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
   SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
-  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 32);
+  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
   SG_ENSURE(ctx->totals, 4 * 8);
   SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
 
@@ -462,7 +464,7 @@ static int run_pass(sg_ctx* ctx) {
   B.out[1] = ctx->out2.as<uint8_t>();
   B.out_cap[0] = ctx->out1.cap;
   B.out_cap[1] = ctx->out2.cap;
-  sg::launch_header(B, s);
+  sg::launch_header(ctx->P, B, s);
   sg::launch_emit(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));
   SG_HIP(hipGetLastError());

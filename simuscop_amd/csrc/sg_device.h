@@ -30,6 +30,7 @@ struct DevProfile {
   const uint32_t* del_row; uint32_t del_lg;
   const uint32_t* isz_row; uint32_t isz_lg;  // isz_row == nullptr -> fixed insert size
   int32_t isz_min, fixed_isz;
+  int32_t isz_lo, isz_hi;      // smallest / largest insert size that can be drawn
   uint32_t Tins;               // insertion iff x <= Tins
   uint32_t Cdel;               // deletion  iff x <  Cdel
   int32_t L, bins, kmer, min_qual;
@@ -66,7 +67,7 @@ struct DevBatch {
   uint32_t* events;             // [2][n_slots][SG_MAX_EVENTS]
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
-  uint4* meta;                  // [2][n_slots][2] per-read rows for the emit kernel (see indel_kernel / header_kernel)
+  uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
   uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] error flags
   uint8_t* out[2];
   uint64_t out_cap[2];

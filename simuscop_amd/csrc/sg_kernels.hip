@@ -77,37 +77,67 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// plan: one lane per window
+// plan: PLAN_S lanes per window.  The reference draws (start, insert size) attempts one after the
+// other and counts failures per window (fragment shorter than a read: Segment.cpp:753-762); attempt t
+// of window w has the address (w, t).  Interior windows cannot fail -- every start leaves at least the
+// largest insert size before the chain end -- so attempt t IS fragment t and the PLAN_S lanes take
+// fragments t = j, j+PLAN_S, ... independently.  Windows near a chain end keep the sequential loop
+// on lane 0.
 // ------------------------------------------------------------------------------------------------
+#define PLAN_S 8
+
+__device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch& B, const sg_window& win, uint64_t w,
+                                             uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)w + B.win_offset, attempt, 0, c3, B.k0, B.k1, x);
+  // threadPool->randomInteger(spos, epos+1): (long)(start + (end-start)*(x/2^32)) in fp64
+  const double frac = __dmul_rn((double)x[0], 1.0 / 4294967296.0);
+  const double v = __dadd_rn((double)win.spos, __dmul_rn((double)win.len, frac));
+  const uint32_t pos = (uint32_t)(long long)v;
+  uint32_t isz;
+  if (B.paired) isz = P.isz_row ? (uint32_t)P.isz_min + row_search(P.isz_row, P.isz_lg, x[1]) : (uint32_t)P.fixed_isz;
+  else isz = win.len;
+  const uint64_t avail = clen - (win.hap_base + pos);
+  const uint32_t flen = avail < (uint64_t)isz ? (uint32_t)avail : isz;
+  const uint32_t strand = B.paired ? 0u : (x[2] >> 31);  // randomInteger(0,2)
+  r.win = (uint32_t)w; r.relpos = pos - win.spos; r.fl = flen | (strand << 31);
+  return flen >= (uint32_t)P.L;
+}
+
 __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
-  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = gid / PLAN_S;
+  const uint32_t j = (uint32_t)(gid % PLAN_S);
   if (w >= B.n_windows) return;
   const sg_window win = B.windows[w];
   const int n = win.n_reads;
   const uint32_t planned = n <= 0 ? 0u : (B.paired ? ((uint32_t)n + 1u) / 2u : (uint32_t)n);
   const uint64_t clen = B.chain_len[win.chain];
   const uint32_t c3 = dev_ctx(KIND_PLAN, 0, B.batch_id);
-  const uint32_t L = (uint32_t)P.L;
+  // can any attempt of this window fail?
+  const uint64_t last_start = win.hap_base + win.spos + win.len - 1u;
+  const uint64_t need = B.paired ? (uint64_t)P.isz_hi : (uint64_t)win.len;
+  const uint32_t shortest = B.paired ? (uint32_t)P.isz_lo : win.len;
+  const bool safe = last_start + need <= clen && shortest >= (uint32_t)P.L;
+  if (safe) {
+    for (uint32_t k = j; k < planned; k += PLAN_S) {
+      PairRec r;
+      plan_attempt(P, B, win, w, k, clen, c3, r);
+      r.k = k;
+      B.pairs[win.slot_base + k] = r;
+    }
+    if (j == 0) B.win_actual[w] = planned;
+    return;
+  }
+  if (j != 0) return;
   uint32_t done = 0, fail = 0, attempt = 0;
   while (done < planned) {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)w + B.win_offset, attempt++, 0, c3, B.k0, B.k1, x);
-    // threadPool->randomInteger(spos, epos+1): (long)(start + (end-start)*(x/2^32)) in fp64
-    double frac = __dmul_rn((double)x[0], 1.0 / 4294967296.0);
-    double v = __dadd_rn((double)win.spos, __dmul_rn((double)win.len, frac));
-    uint32_t pos = (uint32_t)(long long)v;
-    uint32_t isz;
-    if (B.paired) isz = P.isz_row ? (uint32_t)P.isz_min + row_search(P.isz_row, P.isz_lg, x[1]) : (uint32_t)P.fixed_isz;
-    else isz = win.len;
-    uint64_t avail = clen - (win.hap_base + pos);
-    uint32_t flen = avail < (uint64_t)isz ? (uint32_t)avail : isz;
-    if (flen < L) {
+    PairRec r;
+    if (!plan_attempt(P, B, win, w, attempt++, clen, c3, r)) {
       if (++fail > 1000) break;
       continue;
     }
-    uint32_t strand = B.paired ? 0u : (x[2] >> 31);  // randomInteger(0,2)
-    PairRec r;
-    r.win = (uint32_t)w; r.relpos = pos - win.spos; r.fl = flen | (strand << 31); r.k = done;
+    r.k = done;
     B.pairs[win.slot_base + done] = r;
     done++;
   }
@@ -152,8 +182,8 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
   if (!flen) {
     B.rlen[idx] = 0; B.reclen[idx] = 0;
-    B.meta[idx * 2] = make_uint4(0, 0, 0, 0);
-    B.meta[idx * 2 + 1] = make_uint4(0, 0, 0, 0);
+    B.meta[idx * 4] = make_uint4(0, 0, 0, 0);
+    B.meta[idx * 4 + 1] = make_uint4(0, 0, 0, 0);
     return;
   }
   const int L = P.L;
@@ -201,29 +231,59 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
   const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
   B.reclen[idx] = hdr + 2u * np + 4u;
-  // Per-read row for the emit kernel.  m0.z/.w carry the name fields until header_kernel has written
-  // the header text and replaces them by the record's byte offset.
+  // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
+  // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
+  // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
   const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
   const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
-  B.meta[idx * 2] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
+  B.meta[idx * 4] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
   // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
   // (sg_load_profile rejects profiles that could violate the bound)
   // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
-  B.meta[idx * 2 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
+  B.meta[idx * 4 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
+  if (hdr <= 32u) {
+    uint32_t* hp = (uint32_t*)(B.meta + idx * 4 + 2);
+    uint32_t w = 0, nb = 0;
+    auto push = [&](uint32_t b) {
+      w |= b << (nb * 8u);
+      if (++nb == 4u) { *hp++ = w; w = 0; nb = 0; }
+    };
+    auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
+      const uint32_t nd = ndigits(v);
+      uint64_t lo = 0;
+      uint32_t hi = 0;
+      for (uint32_t k = 0; k < nd; k++) {
+        const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
+        if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
+        v = qd;
+      }
+      for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
+      for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
+    };
+    for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);  // hdr <= 32 implies prefix <= 16
+    push_dec(namepos);
+    push('#');
+    push_dec(fragcount);
+    if (B.paired) { push('/'); push('1' + m); }
+    push('\n');
+    if (nb) *hp = w;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// header: one lane per read, after the offset scan.  Writes "@popu#chr#pos%segsize#fragCount[/m]\n"
-// (Segment.cpp:780,809,824) straight to HBM (~27 bytes per record) and completes the read's row.
+// header (fallback): one lane per read, after the offset scan.  The fast emit kernel stores header
+// texts of <= 32 bytes itself (from the read's row); this kernel serves the generic emit kernel and
+// over-long headers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void header_kernel(DevBatch B) {
+__global__ __launch_bounds__(256) void header_kernel(DevBatch B, uint32_t only_long) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
   if (t >= B.n_slots) return;
   const size_t idx = (size_t)m * B.n_slots + t;
-  uint4 m0 = B.meta[idx * 2];
-  const uint4 m1 = B.meta[idx * 2 + 1];
+  const uint4 m1 = B.meta[idx * 4 + 1];
   if (!(m1.x & 0x7FFFFFFFu)) return;
+  if (only_long && (m1.y >> 20) <= 32u) return;  // written by the emit kernel from the row
+  const uint4 m0 = B.meta[idx * 4];
   const uint64_t ooff = B.recoff[idx];
   if (ooff + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
   const uint32_t namepos = m0.z, fragcount = m0.w;
@@ -259,9 +319,6 @@ __global__ __launch_bounds__(256) void header_kernel(DevBatch B) {
     push('\n');
     for (uint32_t i = 0; i < nb; i++) hp[i] = (uint8_t)(w >> (8u * i));
   }
-  m0.z = (uint32_t)ooff;
-  m0.w = (uint32_t)(ooff >> 32);
-  B.meta[idx * 2] = m0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -631,8 +688,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
     if (lane < G && t < B.n_slots) {
       const size_t idx = (size_t)m * B.n_slots + t;
-      my0 = B.meta[idx * 2];
-      my1 = B.meta[idx * 2 + 1];
+      my0 = B.meta[idx * 4];
+      my1 = B.meta[idx * 4 + 1];
+      const uint64_t ooff = B.recoff[idx];
+      my0.z = (uint32_t)ooff;
+      my0.w = (uint32_t)(ooff >> 32);
       if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;  // ceil((np + 3) / 8): bases + "\n+\n"
     }
     meta_rows[lane * 2] = my0;
@@ -855,8 +915,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
     if (lane < G && t < B.n_slots) {
       const size_t idx = (size_t)m * B.n_slots + t;
-      my0 = B.meta[idx * 2];
-      my1 = B.meta[idx * 2 + 1];
+      my0 = B.meta[idx * 4];
+      my1 = B.meta[idx * 4 + 1];
+      const uint64_t ooff = B.recoff[idx];
+      my0.z = (uint32_t)ooff;
+      my0.w = (uint32_t)(ooff >> 32);
       if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;
     }
     meta_rows[lane * 2] = my0;
@@ -908,6 +971,28 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         if (cb >= nitems) { more &= more - 1ull; cb = TI; }
       }
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+      // the read's first item lane also stores its header text (<= 32 bytes, from the read's row);
+      // the line it lands on is completed by the bases stored right after, so it merges in L2
+      if (active && c == 0u && step < nmain && (m1.y >> 20) <= 32u) {
+        const uint32_t hl = m1.y >> 20;
+        const uint4* hrow = B.meta + ((size_t)m * B.n_slots + (g * G + r)) * 4 + 2;
+        const uint4 h0 = hrow[0], h1 = hrow[1];
+        uint8_t* ro = B.out[m] + (((uint64_t)m0.w << 32) | m0.z);
+        uint8_t* q = ro;
+        uint32_t rem = hl;
+        uint4 part = h0;
+        if (hl >= 16u) { __builtin_memcpy(q, &h0, 16); q += 16; rem -= 16u; part = h1; }
+        if (rem == 16u) {
+          __builtin_memcpy(q, &part, 16);
+        } else {  // 0..15 bytes left: 8/4/2/1 pieces, consumed from a shifting 128-bit value
+          uint64_t a = ((uint64_t)part.y << 32) | part.x;
+          const uint64_t b = ((uint64_t)part.w << 32) | part.z;
+          if (rem & 8u) { __builtin_memcpy(q, &a, 8); q += 8; a = b; }
+          if (rem & 4u) { const uint32_t v = (uint32_t)a; __builtin_memcpy(q, &v, 4); q += 4; a >>= 32; }
+          if (rem & 2u) { const uint16_t v = (uint16_t)a; __builtin_memcpy(q, &v, 2); q += 2; a >>= 16; }
+          if (rem & 1u) *q = (uint8_t)a;
+        }
+      }
       const bool slow = fast_item<PAIRED>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
                                           active, o0, a0, k0_, o1, a1, k1_);
       // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
@@ -988,7 +1073,7 @@ __global__ __launch_bounds__(256) void gc_kernel(const uint8_t* __restrict__ cha
 // ------------------------------------------------------------------------------------------------
 void launch_plan(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_windows) return;
-  uint32_t grid = (uint32_t)((B.n_windows + 255) / 256);
+  uint32_t grid = (uint32_t)((B.n_windows * PLAN_S + 255) / 256);
   hipLaunchKernelGGL(plan_kernel, dim3(grid), dim3(256), 0, s, P, B);
 }
 void launch_namebase(const DevBatch& B, hipStream_t s) {
@@ -1000,10 +1085,14 @@ void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
   hipLaunchKernelGGL(indel_kernel, grid, dim3(256), 0, s, P, B);
 }
-void launch_header(const DevBatch& B, hipStream_t s) {
+bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
+void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
+  const bool fast = emit_uses_fast_kernel(P, B);
+  // fast kernel: headers <= 32 bytes come from the rows; 24 bytes beyond the prefix is the longest tail
+  if (fast && B.prefix_len + 24u <= 32u) return;
   dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
-  hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B);
+  hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B, fast ? 1u : 0u);
 }
 uint32_t scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s) {
@@ -1022,17 +1111,31 @@ static void launch_emit_variant(const DevProfile& P, const DevBatch& B, dim3 gri
   (void)hipFuncSetAttribute((const void*)emit_kernel<KT, QLG, SL, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((emit_kernel<KT, QLG, SL, QL>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
 }
-void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
-  if (!B.n_slots) return;
+struct EmitLds { uint32_t sub_rows, qual_words; size_t lds; bool sub_lds, qual_lds; };
+static EmitLds emit_lds(const DevProfile& P) {
+  EmitLds e;
   uint32_t kmer_count = 0;
   for (int m = 1, p = 1; m <= P.kmer; m++) { p *= 4; kmer_count += p; }
-  const uint32_t sub_rows = kmer_count * (uint32_t)P.bins;
-  const uint32_t qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
+  e.sub_rows = kmer_count * (uint32_t)P.bins;
+  e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
   const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4;
-  const size_t sub_b = (size_t)sub_rows * 16, qual_b = ((size_t)qual_words * 4 + 15) & ~(size_t)15;
-  const bool sub_lds = fixed + sub_b <= kLdsBytes;
-  const bool qual_lds = sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
-  const size_t lds = fixed + (sub_lds ? sub_b : 0) + (qual_lds ? qual_b : 0);
+  const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
+  e.sub_lds = fixed + sub_b <= kLdsBytes;
+  e.qual_lds = e.sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
+  e.lds = fixed + (e.sub_lds ? sub_b : 0) + (e.qual_lds ? qual_b : 0);
+  return e;
+}
+bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
+  (void)B;
+  const EmitLds e = emit_lds(P);
+  return P.kmer == 3 && P.qual_lg == 3 && e.sub_lds && e.qual_lds && getenv("SG_DIAG") == nullptr;
+}
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
+  if (!B.n_slots) return;
+  const EmitLds e = emit_lds(P);
+  const uint32_t sub_rows = e.sub_rows, qual_words = e.qual_words;
+  const size_t lds = e.lds;
+  const bool sub_lds = e.sub_lds, qual_lds = e.qual_lds;
   // fixed lane map: TI items of 8 bases per read, RPI reads per wave iteration
   uint32_t TI = ((uint32_t)P.L + 3u + 7u) / 8u;
   if (TI > 64u) TI = 64u;  // longer reads finish in the clean-up loop
@@ -1048,7 +1151,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
   dim3 grid(gx, nm);
-  const bool fast = P.kmer == 3 && P.qual_lg == 3 && sub_lds && qual_lds && getenv("SG_DIAG") == nullptr;
+  const bool fast = emit_uses_fast_kernel(P, B);
   if (fast) {
     if (B.paired) {
       (void)hipFuncSetAttribute((const void*)emit_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
