@@ -41,10 +41,10 @@ def cpu_baseline(workdir, cores):
     """Time the reference's CPU thread-pool path on a bounded sample of the same workload.
 
     Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
-    Fallback (binary absent): the oracle restatement (kind "port").  Sample: a 16 Mbp contig of the
+    Fallback (binary absent): the oracle restatement (kind "port").  Sample: a 48 Mbp contig of the
     same synthetic genome at 30x (one <=1 Mbp segment per worker thread, Genome.cpp:876-883)."""
     from simuscop_amd import synth
-    sample_len = 16_000_000
+    sample_len = 48_000_000   # ~15 s of reference CPU time on 16 threads
     fa = os.path.join(workdir, "cpu_sample.fa")
     synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
     cfg = os.path.join(workdir, "cpu_config.txt")
@@ -72,6 +72,28 @@ def cpu_baseline(workdir, cores):
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": kind,
             "sample": f"{sample_len} bp contig, XTen PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
                       f"(whole run incl. input load, threads={cores})"}
+
+
+def pmc_traffic(pairs_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*/pmc_summary.json; FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same bench).  gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request
+    for wide coalesced reads -> doubled; both counters are in KiB."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if "emit_fast_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                best = (path, v)
+    if not best:
+        return None, None
+    path, v = best
+    traffic = (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+    return traffic, os.path.relpath(path, ROOT)
 
 
 def main():
@@ -186,8 +208,10 @@ def main():
                                    f"(151 bp), PE, {args.coverage}x, insertSize 350",
                        "pairs_per_step_per_gpu": pairs_per_step, "parallelism": f"{world} x 1 chromosome shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "emit_kernel", "kernel_ms": emit_ms,
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(pairs_per_step)[0],
+                         "traffic_unit": "bytes per launch", "traffic_source": pmc_traffic(pairs_per_step)[1],
+                         "algorithmic_bytes_per_launch": pairs_per_step * bytes_per_pair,
+                         "kernel": "emit_fast_kernel", "kernel_ms": emit_ms,
                          "algorithmic_bytes_per_pair": bytes_per_pair, "bytes_note": BYTES_PER_PAIR_FMT},
             "kernel_ms_per_step": {k: v / args.steps for k, v in kms.items()},
         }
