@@ -823,7 +823,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 #pragma unroll
   for (int h = 0; h < 4; h++) philox4x32_10(slot + B.slot_offset, 4u * c + (uint32_t)h, 0, c3b, B.k0, B.k1, x + 4 * h);
 
-  uint32_t sw[2] = {0, 0}, qw[2] = {0, 0};
+  uint32_t ksel[2] = {0, 0}, qw[2] = {0, 0};
   const uint32_t ib0 = __umul24(i0, bins);
 #pragma unroll
   for (int h = 0; h < 8; h++) {
@@ -833,7 +833,9 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     if (h == 0) kv = __builtin_amdgcn_ubfe(cw, hoff0, hw0) + hk0;
     else if (h == 1) kv = __builtin_amdgcn_ubfe(cw, hoff1, hw1) + hk1;
     else kv = ((cw >> (2 * h + 6)) & 63u) + 20u;
-    const uint32_t bin = min(__umulhi(ib0 + (uint32_t)h * bins, inv), bins - 1u);  // i*binCount/n'
+    // i*binCount/n'.  Idle lanes may compute a bin past the table: LDS reads beyond the allocation
+    // return 0 and their results are never stored.
+    const uint32_t bin = __umulhi(ib0 + (uint32_t)h * bins, inv);
     const uint4 row = lds_sub[__umul24(kv, bins) + bin];
     const uint32_t k = max((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z), row.w);
     const uint32_t cd = (cw >> (2 * h + 10)) & 3u;
@@ -841,11 +843,16 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
     pos += (xq > qrow[pos + 1]) ? 2u : 0u;
     pos += (xq > qrow[pos]) ? 1u : 0u;
-    const uint32_t sym = (qrow[8 + (pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-    const uint32_t ch = (P.bases_packed >> (8u * k)) & 0xFFu;
-    sw[h >> 2] |= ch << (8 * (h & 3));
-    qw[h >> 2] |= ((uint32_t)P.min_qual + sym) << (8 * (h & 3));
+    const uint32_t sym = ((const uint8_t*)(qrow + 8))[pos];  // one ds_read_u8
+    ksel[h >> 2] |= k << (8 * (h & 3));
+    qw[h >> 2] |= sym << (8 * (h & 3));
   }
+  // called base characters: byte select from `bases` by the packed codes, quality symbols -> ASCII
+  uint32_t sw[2];
+  sw[0] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[0]);
+  sw[1] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[1]);
+  qw[0] += 0x01010101u * (uint32_t)P.min_qual;
+  qw[1] += 0x01010101u * (uint32_t)P.min_qual;
   if (go) {
     uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
     uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
