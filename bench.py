@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -114,10 +115,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if os.environ.get("BENCH_SAME_DEVICE"):   # rehearsal on a 1-GPU box: every rank on device 0 (gloo only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import simuscop_amd
     from simuscop_amd import synth
@@ -146,7 +153,7 @@ def main():
     my_wl = sess.weighted_length()
     from simuscop_amd import dist as sdist
     # all_gather of one fp64 pair per rank (RCCL over xGMI), then the reference's apportioning formula
-    my_reads, _ = sdist.balance_reads(my_wl, args.contig_len, args.coverage, L, device="cuda")
+    my_reads, _ = sdist.balance_reads(my_wl, args.contig_len, args.coverage, L, device=coll_dev)
     sess.set_reads(my_reads)
     assert sess.prepare_batch(0)
     stream = torch.cuda.current_stream()
@@ -177,7 +184,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=coll_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -187,6 +194,7 @@ def main():
         dt_max, total_pairs = dt, float(pairs)
 
     if rank == 0:
+        default_workload = args.contig_len == CHR20_LEN and args.coverage == 30
         pairs_per_step = pairs / args.steps
         emit_ms = kms["emit"] / args.steps
         bytes_per_pair = 2 * L + fq_bytes / max(pairs_per_step, 1)   # measured FASTQ bytes/pair + 2L reference bytes
@@ -204,12 +212,15 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU (GRCh38 chr20 length), HiSeqXTen profile "
+            "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU" + (" (GRCh38 chr20 length)" if args.contig_len == CHR20_LEN else "") + ", HiSeqXTen profile "
                                    f"(151 bp), PE, {args.coverage}x, insertSize 350",
                        "pairs_per_step_per_gpu": pairs_per_step, "parallelism": f"{world} x 1 chromosome shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic(pairs_per_step)[0],
-                         "traffic_unit": "bytes per launch", "traffic_source": pmc_traffic(pairs_per_step)[1],
+                         "frac": achieved / 8000.0,
+                         # PMC traffic was collected on the default workload only
+                         "traffic": pmc_traffic(pairs_per_step)[0] if default_workload else None,
+                         "traffic_unit": "bytes per launch",
+                         "traffic_source": pmc_traffic(pairs_per_step)[1] if default_workload else None,
                          "algorithmic_bytes_per_launch": pairs_per_step * bytes_per_pair,
                          "kernel": "emit_fast_kernel", "kernel_ms": emit_ms,
                          "algorithmic_bytes_per_pair": bytes_per_pair, "bytes_note": BYTES_PER_PAIR_FMT},
