@@ -64,7 +64,7 @@ struct sg_ctx {
   bool results_valid = false;
 
   bool profiling = false;
-  hipEvent_t evs[SG_K_COUNT + 1] = {};
+  hipEvent_t evs[SG_K_COUNT + 2] = {};  // starts of plan..scan, end of scan, start/end of emit
   bool evs_created = false;
   float last_ms[SG_K_COUNT] = {0, 0, 0, 0, 0};
 
@@ -212,7 +212,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   }
   // odd row stride: consecutive rows start on different LDS banks (an even stride of 10 words put
   // every first probe on 16 of the 32 banks: 62 % of LDS cycles were conflicts)
-  const uint32_t qW = sg::pow2_at_least(wmax), qstride = (qW + qW / 4) | 1u;
+  const uint32_t qW = (wmax + 3u) & ~3u, qstride = (qW + qW / 4) | 1u;  // width: multiple of 4, not a power of two
   const size_t qual_off = tab.size();
   tab.resize(qual_off + qrows * qstride, 0xFFFFFFFFu);
   for (size_t r = 0; r < qrows; r++) {
@@ -276,7 +276,8 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   P.sub_mate_rows = has2 ? (uint32_t)sub_rows : 0u;
   P.qual = base + qual_off;
   P.qual_stride = qstride;
-  P.qual_lg = sg::log2u(qW);
+  P.qual_lg = sg::log2u(sg::pow2_at_least(qW));
+  P.qual_w = qW;
   P.ins_row = base + ins_off; P.ins_lg = ins_lg;
   P.del_row = base + del_off; P.del_lg = del_lg;
   P.isz_row = has_isz ? base + isz_off : nullptr; P.isz_lg = isz_lg;
@@ -464,9 +465,10 @@ static int run_pass(sg_ctx* ctx) {
   B.out[1] = ctx->out2.as<uint8_t>();
   B.out_cap[0] = ctx->out1.cap;
   B.out_cap[1] = ctx->out2.cap;
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));  // after the (first-pass) output allocation
   sg::launch_header(ctx->P, B, s);
   sg::launch_emit(ctx->P, B, s);
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[6], s));
   SG_HIP(hipGetLastError());
   ctx->sampled = true;
   ctx->results_valid = false;
@@ -486,7 +488,8 @@ int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_f
   SG_HIP(hipSetDevice(ctx->device));
   SG_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->profiling) {
-    for (int i = 0; i < SG_K_COUNT; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
+    for (int i = 0; i < SG_K_COUNT - 1; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
+    SG_HIP(hipEventElapsedTime(&ctx->last_ms[SG_K_EMIT], ctx->evs[5], ctx->evs[6]));
   }
   ctx->results_valid = true;
   if (bytes_r1) *bytes_r1 = ctx->host_totals[0];

@@ -24,8 +24,8 @@ __host__ __device__ inline uint32_t ev_pack(uint32_t j, uint32_t len, uint32_t d
 struct DevProfile {
   const uint4* sub;            // [mate][kmer_count][bins] rows {T0,T1,T2,k0}
   uint32_t sub_mate_rows;      // rows per mate table (0 when mate 2 shares mate 1's table)
-  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {T0..T(W-1), sym bytes packed 4 per word}, W = 1<<qual_lg
-  uint32_t qual_stride, qual_lg;
+  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {T0..T(W-1), sym bytes packed 4 per word}
+  uint32_t qual_stride, qual_lg, qual_w;  // W = qual_w (multiple of 4), qual_lg = ceil(log2 W) search steps
   const uint32_t* ins_row; uint32_t ins_lg;
   const uint32_t* del_row; uint32_t del_lg;
   const uint32_t* isz_row; uint32_t isz_lg;  // isz_row == nullptr -> fixed insert size

@@ -55,13 +55,15 @@ __device__ __forceinline__ uint32_t row_search(const uint32_t* __restrict__ row,
   return row[0] + pos;
 }
 
-// quality row {T0..T(W-1), sym bytes}: symbol of the first threshold >= x
-__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ row, uint32_t lg, uint32_t x) {
+// quality row {T0..T(W-1), sym bytes}: symbol of the first threshold >= x.  W is a multiple of 4 but
+// not necessarily a power of two: probes past the row count as +infinity.
+__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ row, uint32_t w, uint32_t lg, uint32_t x) {
   uint32_t pos = 0;
-  for (uint32_t step = lg ? (1u << (lg - 1)) : 0; step; step >>= 1)
-    if (x > row[pos + step - 1]) pos += step;
-  const uint32_t w = row[(1u << lg) + (pos >> 2)];
-  return (w >> (8u * (pos & 3u))) & 0xFFu;
+  for (uint32_t step = lg ? (1u << (lg - 1)) : 0; step; step >>= 1) {
+    const uint32_t i = pos + step - 1;
+    if (i < w && x > row[i]) pos += step;
+  }
+  return ((const uint8_t*)(row + w))[pos];
 }
 
 __device__ __forceinline__ uint32_t aux_draw(const DevBatch& B, uint32_t slot, uint32_t j, uint32_t f, uint32_t mate) {
@@ -634,7 +636,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
       pos += (xq > qrow[pos]) ? 1u : 0u;
       qi = (qrow[8 + (pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
     } else {
-      qi = qual_lookup(qrow, P.qual_lg, xq);
+      qi = qual_lookup(qrow, P.qual_w, P.qual_lg, xq);
     }
     uint32_t ch = kvalid ? ((P.bases_packed >> (8u * kk)) & 0xFFu) : (uint32_t)'N';
     uint32_t q = (uint32_t)P.min_qual + (kvalid ? qi : __umulhi(xq, 20u));  // getRandBaseQuality, Profile.cpp:1582-1584
@@ -753,7 +755,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..
   return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
 }
 
-template <bool PAIRED>
+template <bool PAIRED, bool DIAG>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
                                           const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
@@ -814,9 +816,6 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
       }
     }
   }
-  const bool slow = active && (bad != 0u || nev >= 2u);  // queued for the generic item code by the caller
-  const bool go = active && !slow;
-
   // ---- four Philox calls: [sub, qual] for 8 bases (counter = i/2) ----
   uint32_t x[16];
   const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
@@ -825,9 +824,11 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 
   uint32_t ksel[2] = {0, 0}, qw[2] = {0, 0};
   const uint32_t ib0 = __umul24(i0, bins);
+  uint32_t offdiag = 0;
+  const uint32_t* qrows[8];
 #pragma unroll
   for (int h = 0; h < 8; h++) {
-    const uint32_t xs = x[2 * h], xq = x[2 * h + 1];
+    const uint32_t xs = x[2 * h];
     // context id in packed digit order; first two bases of a read use the short-context blocks
     uint32_t kv;
     if (h == 0) kv = __builtin_amdgcn_ubfe(cw, hoff0, hw0) + hk0;
@@ -839,14 +840,42 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     const uint4 row = lds_sub[__umul24(kv, bins) + bin];
     const uint32_t k = max((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z), row.w);
     const uint32_t cd = (cw >> (2 * h + 10)) & 3u;
-    const uint32_t* qrow = lds_qual + __umul24(__umul24((cd << 2) | k, bins) + bin, P.qual_stride);
-    uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
-    pos += (xq > qrow[pos + 1]) ? 2u : 0u;
-    pos += (xq > qrow[pos]) ? 1u : 0u;
-    const uint32_t sym = ((const uint8_t*)(qrow + 8))[pos];  // one ds_read_u8
     ksel[h >> 2] |= k << (8 * (h & 3));
-    qw[h >> 2] |= sym << (8 * (h & 3));
+    if (DIAG) {
+      // only the (reference base == called base) quality rows live in LDS; an item with a substitution
+      // is finished by the generic code
+      offdiag |= k ^ ((P.remap_packed >> (2u * cd)) & 3u);
+      qrows[h] = lds_qual + __umul24(__umul24(cd, bins) + bin, P.qual_stride);
+    } else {
+      qrows[h] = lds_qual + __umul24(__umul24((cd << 2) | k, bins) + bin, P.qual_stride);
+    }
   }
+  if (!DIAG) {
+#pragma unroll
+    for (int h = 0; h < 8; h++) {  // 8-wide rows: three probes, then the symbol byte
+      const uint32_t xq = x[2 * h + 1];
+      const uint32_t* qrow = qrows[h];
+      uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
+      pos += (xq > qrow[pos + 1]) ? 2u : 0u;
+      pos += (xq > qrow[pos]) ? 1u : 0u;
+      qw[h >> 2] |= (uint32_t)((const uint8_t*)(qrow + 8))[pos] << (8 * (h & 3));
+    }
+  } else {
+    // rows of P.qual_w symbols: qual_lg probe rounds, the 8 bases' probes of a round are independent
+    uint32_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t step = 1u << (P.qual_lg - 1u); step; step >>= 1) {
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const uint32_t i = pos[h] + step - 1u;
+        const uint32_t t = i < P.qual_w ? qrows[h][i] : 0xFFFFFFFFu;
+        pos[h] += (x[2 * h + 1] > t) ? step : 0u;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h++) qw[h >> 2] |= (uint32_t)((const uint8_t*)(qrows[h] + P.qual_w))[pos[h]] << (8 * (h & 3));
+  }
+  const bool slow = active && (bad != 0u || nev >= 2u || offdiag != 0u);  // queued for the generic item code by the caller
+  const bool go = active && !slow;
   // called base characters: byte select from `bases` by the packed codes, quality symbols -> ASCII
   uint32_t sw[2];
   sw[0] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[0]);
@@ -880,7 +909,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
 
-template <bool PAIRED>
+template <bool PAIRED, bool DIAG>
 __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
                                                                  uint32_t TI, uint32_t RPI) {
   extern __shared__ uint4 smem[];
@@ -899,9 +928,19 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     lds_sub[i] = gsub[(size_t)P.sub_perm[d] * bins + b];
   }
   const uint32_t qrow_words = 4u * bins * P.qual_stride;  // rows of one reference base
-  for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {
-    const uint32_t cdn = i / qrow_words, rest = i - cdn * qrow_words;
-    lds_qual[i] = P.qual[((P.remap_packed >> (2u * cdn)) & 3u) * qrow_words + rest];
+  if (!DIAG) {
+    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {
+      const uint32_t cdn = i / qrow_words, rest = i - cdn * qrow_words;
+      lds_qual[i] = P.qual[((P.remap_packed >> (2u * cdn)) & 3u) * qrow_words + rest];
+    }
+  } else {
+    // diagonal rows only: LDS row (cdn, bin) <- table row (ref = called = profile code of cdn, bin)
+    const uint32_t drow_words = bins * P.qual_stride;
+    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {  // qual_words = 4 * drow_words here
+      const uint32_t cdn = i / drow_words, rest = i - cdn * drow_words;
+      const uint32_t pc = (P.remap_packed >> (2u * cdn)) & 3u;
+      lds_qual[i] = P.qual[pc * qrow_words + pc * drow_words + rest];
+    }
   }
   __syncthreads();
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
@@ -1000,7 +1039,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           if (rem & 1u) *q = (uint8_t)a;
         }
       }
-      const bool slow = fast_item<PAIRED>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
+      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
                                           active, o0, a0, k0_, o1, a1, k1_);
       // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
       const unsigned long long sm = __ballot(slow);
@@ -1118,24 +1157,36 @@ static void launch_emit_variant(const DevProfile& P, const DevBatch& B, dim3 gri
   (void)hipFuncSetAttribute((const void*)emit_kernel<KT, QLG, SL, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((emit_kernel<KT, QLG, SL, QL>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
 }
-struct EmitLds { uint32_t sub_rows, qual_words; size_t lds; bool sub_lds, qual_lds; };
+struct EmitLds { uint32_t sub_rows, qual_words, diag_words; size_t lds, lds_diag; bool sub_lds, qual_lds, diag_lds; };
 static EmitLds emit_lds(const DevProfile& P) {
   EmitLds e;
   uint32_t kmer_count = 0;
   for (int m = 1, p = 1; m <= P.kmer; m++) { p *= 4; kmer_count += p; }
   e.sub_rows = kmer_count * (uint32_t)P.bins;
   e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
+  e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
   const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4;
   const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
+  const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
   e.sub_lds = fixed + sub_b <= kLdsBytes;
   e.qual_lds = e.sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
+  e.diag_lds = e.sub_lds && fixed + sub_b + diag_b <= kLdsBytes;
   e.lds = fixed + (e.sub_lds ? sub_b : 0) + (e.qual_lds ? qual_b : 0);
+  e.lds_diag = fixed + sub_b + diag_b;
   return e;
+}
+// 0: generic kernel, 1: fast kernel with the whole 8-wide quality table in LDS, 2: fast kernel with the
+// diagonal quality rows in LDS (wide quality alphabets)
+static int emit_fast_mode(const DevProfile& P) {
+  const EmitLds e = emit_lds(P);
+  if (P.kmer != 3 || getenv("SG_DIAG") != nullptr) return 0;
+  if (P.qual_w == 8 && e.sub_lds && e.qual_lds) return 1;
+  if (P.qual_w <= 64 && e.diag_lds) return 2;
+  return 0;
 }
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
   (void)B;
-  const EmitLds e = emit_lds(P);
-  return P.kmer == 3 && P.qual_lg == 3 && e.sub_lds && e.qual_lds && getenv("SG_DIAG") == nullptr;
+  return emit_fast_mode(P) != 0;
 }
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
@@ -1158,16 +1209,18 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
   dim3 grid(gx, nm);
-  const bool fast = emit_uses_fast_kernel(P, B);
-  if (fast) {
-    if (B.paired) {
-      (void)hipFuncSetAttribute((const void*)emit_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((emit_fast_kernel<true>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
-    } else {
-      (void)hipFuncSetAttribute((const void*)emit_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((emit_fast_kernel<false>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
-    }
-  } else if (P.kmer == 3 && P.qual_lg == 3 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  const int mode = emit_fast_mode(P);
+  auto launch_fast = [&](auto kern, size_t bytes, uint32_t qwords) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(EMIT_THREADS), bytes, s, P, B, sub_rows, qwords, TI, RPI);
+  };
+  if (mode == 1) {
+    if (B.paired) launch_fast(emit_fast_kernel<true, false>, lds, qual_words);
+    else launch_fast(emit_fast_kernel<false, false>, lds, qual_words);
+  } else if (mode == 2) {
+    if (B.paired) launch_fast(emit_fast_kernel<true, true>, e.lds_diag, e.diag_words);
+    else launch_fast(emit_fast_kernel<false, true>, e.lds_diag, e.diag_words);
+  } else if (P.kmer == 3 && P.qual_w == 8 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else launch_emit_variant<0, 0, false, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
