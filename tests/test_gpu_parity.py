@@ -69,3 +69,23 @@ def test_sharded_run_equals_unsharded(tmp_path):
             got += recs
         assert nonempty >= 2
         assert sorted(whole) == sorted(got), f
+
+
+def test_launcher_two_ranks_merge(tmp_path):
+    """simuscop_amd.run with two ranks (gloo rehearsal, both on device 0): merged output holds exactly the
+    records of the single-process run."""
+    import sys
+    cfg = cases.build_case("wes_pe_targets", str(tmp_path))
+    one = str(tmp_path / "one")
+    _run_gpu(cfg, one)
+    env = dict(os.environ, SIMUSCOP_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", "-m", "simuscop_amd.run", cfg,
+                        "--seed", str(SEED), "--merge", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_dir = [l.split("=", 1)[1].strip() for l in open(cfg) if l.startswith("output")][0]
+    for f in _files(one):
+        whole = _records(open(os.path.join(one, f), "rb").read())
+        merged = _records(open(os.path.join(out_dir, f), "rb").read())
+        assert sorted(whole) == sorted(merged), f
