@@ -1017,14 +1017,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         if (cb >= nitems) { more &= more - 1ull; cb = TI; }
       }
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
-      // the read's first item lane also stores its header text (<= 32 bytes, from the read's row);
-      // the line it lands on is completed by the bases stored right after, so it merges in L2
-      if (active && c == 0u && step < nmain && (m1.y >> 20) <= 32u) {
-        const uint32_t hl = m1.y >> 20;
+      // the read's first item lane also stores its header text (<= 32 bytes, from the read's row); the
+      // line it lands on is completed by the bases stored by the same wave, so it merges in L2.  The row
+      // loads are issued before the sampling code and consumed after it (latency hidden).
+      const bool hdr_lane = active && c == 0u && step < nmain && (m1.y >> 20) <= 32u;
+      uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
+      if (hdr_lane) {
         const uint4* hrow = B.meta + ((size_t)m * B.n_slots + (g * G + r)) * 4 + 2;
-        const uint4 h0 = hrow[0], h1 = hrow[1];
-        uint8_t* ro = B.out[m] + (((uint64_t)m0.w << 32) | m0.z);
-        uint8_t* q = ro;
+        h0 = hrow[0];
+        h1 = hrow[1];
+      }
+      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
+                                          active, o0, a0, k0_, o1, a1, k1_);
+      if (hdr_lane) {
+        const uint32_t hl = m1.y >> 20;
+        uint8_t* q = B.out[m] + (((uint64_t)m0.w << 32) | m0.z);
         uint32_t rem = hl;
         uint4 part = h0;
         if (hl >= 16u) { __builtin_memcpy(q, &h0, 16); q += 16; rem -= 16u; part = h1; }
@@ -1039,8 +1046,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           if (rem & 1u) *q = (uint8_t)a;
         }
       }
-      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
-                                          active, o0, a0, k0_, o1, a1, k1_);
       // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
       const unsigned long long sm = __ballot(slow);
       if (sm) {
