@@ -6,6 +6,24 @@
 
 namespace simu {
 
+namespace {
+// Non-inserting lookups: haplotypes of different chromosomes are built concurrently, so the shared
+// maps must never be touched through operator[].
+template <class V>
+const std::vector<V>& lookup(const std::map<std::string, std::vector<V>>& m, const std::string& k) {
+  static const std::vector<V> empty;
+  auto it = m.find(k);
+  return it == m.end() ? empty : it->second;
+}
+template <class V>
+const std::vector<V>& lookup2(const std::map<std::string, std::map<std::string, std::vector<V>>>& m,
+                              const std::string& a, const std::string& b) {
+  static const std::vector<V> empty;
+  auto it = m.find(a);
+  return it == m.end() ? empty : lookup(it->second, b);
+}
+}  // namespace
+
 long Genome::chrom_len(const std::string& chr) const {  // Genome::getChromLen, Genome.cpp:383-396
   if (std::find(chromosomes.begin(), chromosomes.end(), chr) == chromosomes.end()) return 0;
   return fa.length(chr);
@@ -139,7 +157,7 @@ void Genome::choose_haplotypes(Segment& g, uint64_t seed, uint32_t ctx24, uint32
 // its complement (running parity per event class).
 void Genome::segment_haplotypes(const std::string& popu, const std::string& chr, Segment& g, std::vector<std::string>& haps) {
   const int ploidy = cfg.ploidy();
-  const std::string& contig = fa.seqs[chr];
+  const std::string& contig = fa.seqs.at(chr);
   const std::string ref = contig.substr(g.start - 1, g.ref_size());
   const unsigned ref_size = (unsigned)ref.size();
   haps.assign(ploidy, std::string());
@@ -159,14 +177,14 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
     for (unsigned t = 0; t < copies; t++) s[sindx + t * ref_size] = c;
   };
   int parity = 0;
-  for (const SNP& snp : snps[chr]) {
+  for (const SNP& snp : lookup(snps, chr)) {
     if (snp.pos < g.start || snp.pos > g.end) continue;
     for (int h = 0; h < ploidy; h++)
       if (carries(h, false, parity)) substitute(h, (int)(snp.pos - g.start), snp.nucleotide);
     parity ^= 1;
   }
   parity = 0;
-  for (const SNV& v : snvs[popu][chr]) {
+  for (const SNV& v : lookup2(snvs, popu, chr)) {
     if (v.pos < g.start || v.pos > g.end) continue;
     const bool homo = v.type == HOMO;
     for (int h = 0; h < ploidy; h++)
@@ -187,7 +205,7 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
     return s;
   };
   parity = 0;
-  for (const Insertion& ins : inserts[popu][chr]) {
+  for (const Insertion& ins : lookup2(inserts, popu, chr)) {
     if (ins.pos < g.start || ins.pos > g.end) continue;
     const bool homo = ins.type == HOMO;
     const int sindx = (int)(ins.pos + 1 - g.start);  // inserted before reference position pos+1
@@ -205,7 +223,7 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
     if (!homo) parity ^= 1;
   }
   parity = 0;
-  for (const Deletion& d : dels[popu][chr]) {
+  for (const Deletion& d : lookup2(dels, popu, chr)) {
     if (d.pos < g.start || d.pos > g.end) continue;
     const bool homo = d.type == HOMO;
     const int sindx = (int)(d.pos - g.start);
@@ -232,7 +250,7 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
 }
 
 void Genome::build_chains(const std::string& popu, const std::string& chr, uint64_t seed) {
-  ChromPlan& plan = plans[popu][chr];
+  ChromPlan& plan = plans.at(popu).at(chr);
   if (plan.chains_built) return;
   const int ploidy = cfg.ploidy();
   plan.chains.assign(ploidy, std::string());
@@ -258,7 +276,7 @@ void Genome::build_chains(const std::string& popu, const std::string& chr, uint6
 }
 
 void Genome::build_windows(const std::string& popu, const std::string& chr) {
-  ChromPlan& plan = plans[popu][chr];
+  ChromPlan& plan = plans.at(popu).at(chr);
   if (plan.windows_built) return;
   const int ploidy = cfg.ploidy();
   auto push = [&](uint32_t spos, uint32_t len, uint32_t hap) {
@@ -267,7 +285,7 @@ void Genome::build_windows(const std::string& popu, const std::string& chr) {
     plan.w_hap.push_back(hap);
   };
   const std::vector<Target>* ts = nullptr;
-  if (!targets.empty()) ts = &targets[chr];
+  if (!targets.empty()) ts = &lookup(targets, chr);
   for (Segment& g : plan.segs) {
     g.w0 = (uint32_t)plan.w_spos.size();
     if (!g.has_seq) {

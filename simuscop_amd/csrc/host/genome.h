@@ -51,7 +51,7 @@ struct Segment {
 struct ChromPlan {  // one (population, chromosome)
   std::vector<Segment> segs;
   std::vector<std::string> chains;  // [ploidy]
-  bool chains_built = false, windows_built = false;
+  bool chains_built = false, windows_built = false, weighed = false;
   std::vector<uint32_t> w_spos, w_len, w_hap;  // Segment::fragStartPos / (End-Start+1) / hapIndxs
   std::vector<double> w_weight;                // Segment::fragWeights
 };

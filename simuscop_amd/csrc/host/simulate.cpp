@@ -11,6 +11,7 @@
 
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -100,9 +101,9 @@ struct Driver {
   // pass 1 for one chromosome: chains, windows, GC%, weights (Segment::getWeightedLength)
   void weigh(const std::string& popu, const std::string& chr) {
     ChromPlan& plan = genome.plans[popu][chr];
-    if (plan.windows_built) return;
+    if (plan.weighed) return;
     auto t0 = Clock::now();
-    genome.build_chains(popu, chr, seed);
+    genome.build_chains(popu, chr, seed);   // no-ops when prebuild() already did them
     genome.build_windows(popu, chr);
     st.t_haplotypes += since(t0);
     t0 = Clock::now();
@@ -132,6 +133,7 @@ struct Driver {
         else plan.w_weight[w] = f * (unsigned long)plan.w_len[w] / (frag * frag);
       }
     }
+    plan.weighed = true;
     st.t_plan += since(t0);
   }
 
@@ -141,8 +143,42 @@ struct Driver {
     return s;
   }
 
+  // Haplotype construction of a population's chromosomes is independent work: the reference does it
+  // serially on the main thread, twice (Genome.cpp:793, :876-878); here once, on `threads` workers.
+  void prebuild(const std::string& popu) {
+    std::vector<std::string> todo;
+    for (const std::string& chr : genome.chromosomes)
+      if (!genome.plans[popu][chr].chains_built) todo.push_back(chr);
+    const size_t nthreads = std::min<size_t>((size_t)std::max<long long>(1, cfg.num["threads"]), todo.size());
+    if (nthreads <= 1) return;  // weigh() builds on demand
+    auto t0 = Clock::now();
+    std::atomic<size_t> next(0);
+    std::mutex err_mu;
+    std::string err;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; t++) {
+      pool.emplace_back([&]() {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= todo.size()) return;
+          try {
+            genome.build_chains(popu, todo[i], seed);
+            genome.build_windows(popu, todo[i]);
+          } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (err.empty()) err = e.what();
+          }
+        }
+      });
+    }
+    for (std::thread& th : pool) th.join();
+    st.t_haplotypes += since(t0);
+    if (!err.empty()) throw Error(err);
+  }
+
   // Genome::setReadCounts, Genome.cpp:783-825
   void set_read_counts(const std::string& popu, long reads) {
+    prebuild(popu);
     std::vector<double> chr_wl;
     double WL = 0;
     for (const std::string& chr : genome.chromosomes) {
