@@ -152,6 +152,11 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
  * sg_kernel_times() then returns the last pass's per-kernel milliseconds (after sg_result).     */
 int sg_set_profiling(sg_ctx* ctx, int enable);
 int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
+/* Diagnostics of the last pass (after sg_result): items the straight-line emit kernel handed to the
+ * generic item code (windows holding a non-ACGT base, reads with >= 2 sequencing indels), and whether
+ * their queue overflowed so that the whole batch was emitted again by the generic kernel.  Results
+ * are identical either way (Profile::predict, Profile.cpp:1520-1650 has one code path).          */
+int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
 
 /* Exact u32 form of the reference's inverse-CDF draw, exposed for tests: number of 32-bit draws
  * x for which randIndx's `r <= c` holds (r = 2.2204e-16 + (1-2.2204e-16)*x/2^32).               */

@@ -22,7 +22,7 @@ SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit"]
 ENGINE_SYMBOLS = [
     "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
     "sg_upload_haplotypes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
-    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
+    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_host_free",
 ]
 
@@ -65,7 +65,8 @@ class SimuStats(C.Structure):
                 ("planned_reads", C.c_uint64), ("windows", C.c_uint64), ("segments", C.c_uint64),
                 ("batches", C.c_uint64), ("t_load", C.c_double), ("t_haplotypes", C.c_double),
                 ("t_plan", C.c_double), ("t_sample", C.c_double), ("t_fetch", C.c_double),
-                ("t_write", C.c_double), ("t_total", C.c_double), ("kernel_ms", C.c_float * 8)]
+                ("t_write", C.c_double), ("t_total", C.c_double), ("kernel_ms", C.c_float * 8),
+                ("queued_items", C.c_uint64), ("requeued_batches", C.c_uint64)]
 
 
 _engine = None
@@ -102,6 +103,7 @@ def load_engine():
     lib.sg_gc_percent.argtypes = [vp, C.POINTER(SgGcWindow), C.c_uint64, C.POINTER(C.c_int32)]
     lib.sg_set_profiling.argtypes = [vp, C.c_int]
     lib.sg_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sg_emit_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     lib.sg_cdf_count_le.argtypes = [C.c_double]
     lib.sg_cdf_count_le.restype = C.c_uint64
     _engine = lib
@@ -228,6 +230,12 @@ class Session:
         ms = (C.c_float * 8)()
         self._sg(self.eng.sg_kernel_times(self.ctx, ms), "sg_kernel_times")
         return {n: float(ms[i]) for i, n in enumerate(SG_K_NAMES)}
+
+    def emit_info(self):
+        """(items handed to the generic item code, whether the batch was re-emitted) of the last pass."""
+        q, r = C.c_uint64(), C.c_int()
+        self._sg(self.eng.sg_emit_info(self.ctx, C.byref(q), C.byref(r)), "sg_emit_info")
+        return q.value, bool(r.value)
 
     def fetch(self, n1: int, n2: int):
         b1 = C.create_string_buffer(max(n1, 1))

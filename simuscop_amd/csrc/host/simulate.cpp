@@ -314,6 +314,11 @@ struct Driver {
       float ms[SG_K_COUNT];
       sg_kernel_times(eng.ctx, ms);
       for (int i = 0; i < SG_K_COUNT; i++) st.kernel_ms[i] += ms[i];
+      uint64_t queued = 0;
+      int requeued = 0;
+      sg_emit_info(eng.ctx, &queued, &requeued);
+      st.queued_items += queued;
+      st.requeued_batches += (uint64_t)requeued;
     }
     st.t_sample += since(t0);
     st.fragments += nf;

@@ -34,6 +34,8 @@ typedef struct simu_stats {
   double t_write;          // file output
   double t_total;
   float kernel_ms[8];      // summed per kernel (SG_K_*)
+  uint64_t queued_items;   // items the fast emit kernel left to the generic item code (sg_emit_info)
+  uint64_t requeued_batches;  // batches emitted again because that queue overflowed
 } simu_stats;
 
 // Returns 0 on success.  On failure returns the exit code the reference would use and writes the

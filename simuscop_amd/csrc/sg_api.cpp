@@ -21,7 +21,8 @@ void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
-void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s);
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic);
+bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
 }  // namespace sg
@@ -59,8 +60,11 @@ struct sg_ctx {
   sg::DevProfile P{};
   sg::DevBatch B{};
   DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
-      recoff, meta, totals, bsum, out1, out2, gcw, gco;
+      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq;
   uint64_t host_totals[4] = {0, 0, 0, 0};
+  uint64_t host_flags[2] = {0, 0};  // totals[3..4] after the emit kernels: flags, slow-queue counts
+  uint64_t slow_items = 0;
+  bool slow_overflow = false;
   bool results_valid = false;
 
   bool profiling = false;
@@ -121,7 +125,7 @@ void sg_destroy(sg_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
-                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco})
+                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq})
     b->release();
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
@@ -393,7 +397,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
   SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
-  SG_ENSURE(ctx->totals, 4 * 8);
+  SG_ENSURE(ctx->totals, 8 * 8);
   SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
 
   if (nw) SG_HIP(hipMemcpyAsync(ctx->windows.p, b->windows, nw * sizeof(sg_window), hipMemcpyHostToDevice, ctx->stream));
@@ -429,6 +433,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   B.recoff = ctx->recoff.as<uint64_t>();
   B.meta = ctx->meta.as<uint4>();
   B.totals = ctx->totals.as<uint64_t>();
+  B.slowq_count = (uint32_t*)(B.totals + 4);
   ctx->have_plan = true;
   ctx->sampled = false;
   ctx->results_valid = false;
@@ -443,7 +448,7 @@ static int run_pass(sg_ctx* ctx) {
   { const char* dg = getenv("SG_DIAG"); B.diag = dg ? (uint32_t)atoi(dg) : 0u; }
   hipStream_t s = ctx->stream;
   const bool prof = ctx->profiling;
-  SG_HIP(hipMemsetAsync(B.totals, 0, 4 * 8, s));
+  SG_HIP(hipMemsetAsync(B.totals, 0, 8 * 8, s));
   if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
   sg::launch_plan(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));
@@ -465,13 +470,36 @@ static int run_pass(sg_ctx* ctx) {
   B.out[1] = ctx->out2.as<uint8_t>();
   B.out_cap[0] = ctx->out1.cap;
   B.out_cap[1] = ctx->out2.cap;
+  // Queue of the items the fast emit kernel leaves to the generic code (windows with a non-ACGT base,
+  // reads with >= 2 sequencing indels): room for every item of ~10 % of the reads.  A batch that
+  // needs more is emitted again by the generic kernel (sg_result), so the size is not a correctness
+  // matter.  SG_SLOWQ_CAP overrides it (tests force the overflow path with it).
+  B.slowq = nullptr;
+  B.slowq_cap = 0;
+  if (sg::emit_uses_fast_kernel(ctx->P, B)) {
+    uint64_t cap = std::max<uint64_t>(1u << 16, 2ull * B.n_slots);
+    if (const char* e = getenv("SG_SLOWQ_CAP")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    cap = std::min<uint64_t>(cap, 1ull << 30);
+    SG_ENSURE(ctx->slowq, cap * 8 * (B.paired ? 2 : 1));
+    B.slowq = ctx->slowq.as<uint2>();
+    B.slowq_cap = (uint32_t)cap;
+  }
   if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));  // after the (first-pass) output allocation
   sg::launch_header(ctx->P, B, s);
-  sg::launch_emit(ctx->P, B, s);
+  sg::launch_emit(ctx->P, B, s, false);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[6], s));
+  SG_HIP(hipMemcpyAsync(ctx->host_flags, B.totals + 3, 2 * 8, hipMemcpyDeviceToHost, s));
   SG_HIP(hipGetLastError());
   ctx->sampled = true;
   ctx->results_valid = false;
+  return SG_OK;
+}
+
+int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->results_valid) return ctx->fail(SG_ERR_INVALID, "sg_emit_info: call sg_result first");
+  if (queued_items) *queued_items = ctx->slow_items;
+  if (requeued) *requeued = ctx->slow_overflow ? 1 : 0;
   return SG_OK;
 }
 
@@ -487,6 +515,15 @@ int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_f
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_result: call sg_sample first");
   SG_HIP(hipSetDevice(ctx->device));
   SG_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ctx->results_valid) {
+    ctx->slow_items = (ctx->host_flags[1] & 0xFFFFFFFFu) + (ctx->host_flags[1] >> 32);
+    ctx->slow_overflow = (ctx->host_flags[0] & 2) != 0;
+    if (ctx->slow_overflow) {  // headers are in place; every item again through the generic kernel
+      sg::launch_emit(ctx->P, ctx->B, ctx->stream, true);
+      SG_HIP(hipGetLastError());
+      SG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
   if (ctx->profiling) {
     for (int i = 0; i < SG_K_COUNT - 1; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
     SG_HIP(hipEventElapsedTime(&ctx->last_ms[SG_K_EMIT], ctx->evs[5], ctx->evs[6]));

@@ -68,7 +68,10 @@ struct DevBatch {
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
   uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
-  uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] error flags
+  uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full)
+  uint2* slowq;                 // [2][slowq_cap] (slot, item) left to emit_slow_kernel by the fast emit kernel
+  uint32_t* slowq_count;        // [2] entries appended per mate (may exceed slowq_cap: overflow)
+  uint32_t slowq_cap;
   uint8_t* out[2];
   uint64_t out_cap[2];
 };

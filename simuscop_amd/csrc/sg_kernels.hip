@@ -975,24 +975,29 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     unsigned long long more = __ballot(items > TI);
     uint32_t cb = TI;
     uint32_t nslow = 0;  // wave-uniform
+    // Items the straight-line code cannot do (non-ACGT window, >= 2 indels) go to the batch's global
+    // queue: one atomic per flush reserves the range; emit_slow_kernel runs the generic code on them
+    // afterwards.  Keeping that code out of this kernel is worth ~14 % (SGPR spills, I-cache).
     auto flush_slow = [&]() {
       wave_lds_sync();
+      uint32_t base = 0;
+      if (lane == 0u) base = atomicAdd(B.slowq_count + m, nslow);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       for (uint32_t b0 = 0; b0 < nslow; b0 += 64u) {
         const uint32_t i = b0 + lane;
-        const bool act = i < nslow;
-        const uint32_t e = slow_list[act ? i : 0u];
-        const uint32_t r = e & 0xFFu, c = e >> 8;
-        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-        emit_item<0, 0, false, false>(P, B, nullptr, nullptr, gsub, m, m0, m1, g * G + r, c, act);
+        if (i < nslow && base + i < B.slowq_cap) {
+          const uint32_t e = slow_list[i];
+          B.slowq[(size_t)m * B.slowq_cap + base + i] = make_uint2(g * G + (e & 0xFFu), e >> 8);
+        }
       }
+      if (lane == 0u && base + nslow > B.slowq_cap) atomicOr((unsigned long long*)(B.totals + 3), 2ull);
       nslow = 0;
       wave_lds_sync();
     };
     for (uint32_t step = 0;; step++) {
-      // one call site for the (large, inlined) generic code: when the queue is nearly full or at the end
       const bool done = step >= nmain && !more;
       if (done || nslow > SLOW_CAP - 64u) {
-        flush_slow();
+        if (nslow) flush_slow();
         if (done) break;
       }
       uint32_t r, c;
@@ -1054,6 +1059,28 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
     }
     wave_lds_sync();
+  }
+}
+
+// The queued items of emit_fast_kernel, one lane each, through the generic item code (tables via L2).
+__global__ __launch_bounds__(256) void emit_slow_kernel(DevProfile P, DevBatch B) {
+  const uint32_t m = blockIdx.y, lane = threadIdx.x & 63u;
+  const uint32_t tm = B.paired ? m : 0u;
+  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
+  uint32_t n = B.slowq_count[m];
+  if (n > B.slowq_cap) n = B.slowq_cap;  // overflow: the host reruns the batch through emit_kernel
+  const uint2* q = B.slowq + (size_t)m * B.slowq_cap;
+  for (uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) & ~63u; b0 < n; b0 += gridDim.x * 256u) {
+    const uint32_t i = b0 + lane;
+    const bool act = i < n;
+    const uint2 e = q[act ? i : b0];
+    const size_t idx = (size_t)m * B.n_slots + e.x;
+    uint4 m0 = B.meta[idx * 4];
+    const uint4 m1 = B.meta[idx * 4 + 1];
+    const uint64_t ooff = B.recoff[idx];
+    m0.z = (uint32_t)ooff;
+    m0.w = (uint32_t)(ooff >> 32);
+    emit_item<0, 0, false, false>(P, B, nullptr, nullptr, gsub, m, m0, m1, e.x, e.y, act);
   }
 }
 
@@ -1193,7 +1220,7 @@ bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
   (void)B;
   return emit_fast_mode(P) != 0;
 }
-void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic) {
   if (!B.n_slots) return;
   const EmitLds e = emit_lds(P);
   const uint32_t sub_rows = e.sub_rows, qual_words = e.qual_words;
@@ -1214,7 +1241,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
   dim3 grid(gx, nm);
-  const int mode = emit_fast_mode(P);
+  const int mode = force_generic ? 0 : emit_fast_mode(P);
   auto launch_fast = [&](auto kern, size_t bytes, uint32_t qwords) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     hipLaunchKernelGGL(kern, grid, dim3(EMIT_THREADS), bytes, s, P, B, sub_rows, qwords, TI, RPI);
@@ -1225,6 +1252,9 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   } else if (mode == 2) {
     if (B.paired) launch_fast(emit_fast_kernel<true, true>, e.lds_diag, e.diag_words);
     else launch_fast(emit_fast_kernel<false, true>, e.lds_diag, e.diag_words);
+  }
+  if (mode != 0) {
+    hipLaunchKernelGGL(emit_slow_kernel, dim3((uint32_t)cus * 4u, nm), dim3(256), 0, s, P, B);
   } else if (P.kmer == 3 && P.qual_w == 8 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);

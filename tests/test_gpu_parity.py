@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI, driven by the C++ host `simuReads`) against the CPU
 oracle in Philox mode, same seed, same inputs.  Bar: FASTQ files byte-identical (integer/byte work)."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -14,9 +15,9 @@ SEED = (cases.FAKE_SEC << 32) | cases.FAKE_NSEC
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(cfg, out, extra=()):
+def _run_gpu(cfg, out, extra=(), env=None):
     r = subprocess.run([SIMU, cfg, "--seed", str(SEED), "--out", out, "--quiet", "--stats", *extra],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stderr
 
@@ -41,6 +42,30 @@ def test_fastq_identical_to_oracle(name, oracle_lib, tmp_path):
             lo = a.rfind(b"\n@", 0, n) + 1
             pytest.fail(f"{name}/{f}: first difference at byte {n} (sizes {len(a)} vs {len(b)})\n"
                         f"oracle: {a[lo:lo + 400]!r}\ngpu:    {b[lo:lo + 400]!r}")
+
+
+def _stat(stderr, key):
+    return int(re.search(key + r"=(\d+)", stderr).group(1))
+
+
+@pytest.mark.parametrize("name", ["wgs_pe_variants", "wgs_se_hs2000"])
+def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
+    """The straight-line emit kernel queues the items it cannot do (non-ACGT windows, >= 2 indels) for
+    emit_slow_kernel; a queue too small makes the engine emit the batch again with the generic kernel.
+    Both routes, and the generic kernel alone (SG_DIAG=0), must write the same bytes."""
+    cfg = cases.build_case(name, str(tmp_path))
+    outs = {}
+    for tag, extra_env in (("queue", {}), ("overflow", {"SG_SLOWQ_CAP": "3"}), ("generic", {"SG_DIAG": "0"})):
+        d = str(tmp_path / tag)
+        err = _run_gpu(cfg, d, env=dict(os.environ, **extra_env))
+        outs[tag] = {f: open(os.path.join(d, f), "rb").read() for f in _files(d)}
+        if tag == "queue":
+            assert _stat(err, "queued_items") > 0 and _stat(err, "requeued_batches") == 0, err
+        if tag == "overflow":
+            assert _stat(err, "requeued_batches") > 0, err
+        if tag == "generic":
+            assert _stat(err, "queued_items") == 0, err
+    assert outs["queue"] == outs["overflow"] == outs["generic"] and outs["queue"]
 
 
 def _records(blob):
