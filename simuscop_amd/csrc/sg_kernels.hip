@@ -759,7 +759,7 @@ template <bool PAIRED, bool DIAG>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
                                           const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
-                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1) {
+                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1, uint4* tail_row) {
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
@@ -882,29 +882,31 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   sw[1] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[1]);
   qw[0] += 0x01010101u * (uint32_t)P.min_qual;
   qw[1] += 0x01010101u * (uint32_t)P.min_qual;
-  if (go) {
-    uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
-    uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
-    uint8_t* qo = so + np + 3u;
+  // A whole item is two 8-byte stores.  The read's last, partial item (np % 8 bases) is parked in the
+  // read's LDS tail row instead: the per-read pass after the step loop merges it with the record
+  // separators, so the byte-granular stores run once per read group rather than in every step.
+  if (active) {
     if (i0 + 8u <= np) {
-      __builtin_memcpy(so, &S, 8);
-      __builtin_memcpy(qo, &Q, 8);
-    } else {
-      // record tail: "\n+\n" after the bases, '\n' after the qualities
-      const int d = (int)np - (int)i0;  // bases in this item: -2 .. 7
-      if (d >= 0) {
-        const uint64_t keep = (1ull << (8 * d)) - 1ull;
-        S = (S & keep) | (0x0A2B0Aull << (8 * d));
-        Q = (Q & keep) | (0x0Aull << (8 * d));
-      } else {
-        S = 0x0A2B0Aull >> (8 * -d);
+      if (go) {
+        const uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
+        uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
+        uint8_t* qo = so + np + 3u;
+        __builtin_memcpy(so, &S, 8);
+        __builtin_memcpy(qo, &Q, 8);
       }
-      const uint32_t ns = min(8u, np + 3u - i0), nq = d >= 0 ? min(8u, (uint32_t)d + 1u) : 0u;
-      for (uint32_t b2 = 0; b2 < ns; b2++) so[b2] = (uint8_t)(S >> (8 * b2));
-      for (uint32_t b2 = 0; b2 < nq; b2++) qo[b2] = (uint8_t)(Q >> (8 * b2));
+    } else {
+      *tail_row = make_uint4(slow ? 0xFFFFFFFFu : sw[0], sw[1], qw[0], qw[1]);  // base characters are never 0xFF
     }
   }
   return slow;
+}
+
+// n (< 16) bytes of the 128-bit value (lo, hi) to q: 8/4/2/1-byte pieces
+__device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, uint32_t n) {
+  if (n & 8u) { __builtin_memcpy(q, &lo, 8); q += 8; lo = hi; }
+  if (n & 4u) { const uint32_t v = (uint32_t)lo; __builtin_memcpy(q, &v, 4); q += 4; lo >>= 32; }
+  if (n & 2u) { const uint16_t v = (uint16_t)lo; __builtin_memcpy(q, &v, 2); q += 2; lo >>= 16; }
+  if (n & 1u) *q = (uint8_t)lo;
 }
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
@@ -921,6 +923,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint32_t* lds_qual = (uint32_t*)(smem + sub_rows);
   uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
+  uint4* tail_all = (uint4*)(slow_all + EMIT_WAVES * SLOW_CAP);
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   // staging with the fast kernel's digit / base-order permutations
   for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
@@ -945,6 +948,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   __syncthreads();
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
+  uint4* tail_rows = tail_all + wv * 64;
 
   const uint32_t G = RPI * (64u / RPI);
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint64_t ooff = B.recoff[idx];
       my0.z = (uint32_t)ooff;
       my0.w = (uint32_t)(ooff >> 32);
-      if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;
+      if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
     }
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
@@ -1016,46 +1020,51 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
       const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
       const uint32_t np = m1.y & 0xFFFFu;
-      const uint32_t nitems = (np + 10u) / 8u;
+      const uint32_t nitems = (np + 7u) / 8u;
       if (step >= nmain) {
         cb += 64u;
         if (cb >= nitems) { more &= more - 1ull; cb = TI; }
       }
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
-      // the read's first item lane also stores its header text (<= 32 bytes, from the read's row); the
-      // line it lands on is completed by the bases stored by the same wave, so it merges in L2.  The row
-      // loads are issued before the sampling code and consumed after it (latency hidden).
-      const bool hdr_lane = active && c == 0u && step < nmain && (m1.y >> 20) <= 32u;
-      uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
-      if (hdr_lane) {
-        const uint4* hrow = B.meta + ((size_t)m * B.n_slots + (g * G + r)) * 4 + 2;
-        h0 = hrow[0];
-        h1 = hrow[1];
-      }
       const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
-                                          active, o0, a0, k0_, o1, a1, k1_);
-      if (hdr_lane) {
-        const uint32_t hl = m1.y >> 20;
-        uint8_t* q = B.out[m] + (((uint64_t)m0.w << 32) | m0.z);
-        uint32_t rem = hl;
-        uint4 part = h0;
-        if (hl >= 16u) { __builtin_memcpy(q, &h0, 16); q += 16; rem -= 16u; part = h1; }
-        if (rem == 16u) {
-          __builtin_memcpy(q, &part, 16);
-        } else {  // 0..15 bytes left: 8/4/2/1 pieces, consumed from a shifting 128-bit value
-          uint64_t a = ((uint64_t)part.y << 32) | part.x;
-          const uint64_t b = ((uint64_t)part.w << 32) | part.z;
-          if (rem & 8u) { __builtin_memcpy(q, &a, 8); q += 8; a = b; }
-          if (rem & 4u) { const uint32_t v = (uint32_t)a; __builtin_memcpy(q, &v, 4); q += 4; a >>= 32; }
-          if (rem & 2u) { const uint16_t v = (uint16_t)a; __builtin_memcpy(q, &v, 2); q += 2; a >>= 16; }
-          if (rem & 1u) *q = (uint8_t)a;
-        }
-      }
+                                          active, o0, a0, k0_, o1, a1, k1_, tail_rows + r);
       // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
         nslow += (uint32_t)__popcll(sm);
+      }
+    }
+    // ---- per-read pass, lane = read: header text, last partial item, record separators ----
+    // These byte-granular stores touch lines the steps above have just written from this wave, so
+    // they merge in L2.  Reads whose last item went to the generic code (0xFFFFFFFF row) get only the
+    // separators here; emit_slow_kernel writes the same separator bytes again (benign).
+    wave_lds_sync();
+    if (lane < G && t < B.n_slots) {
+      const uint4 r0 = meta_rows[lane * 2], r1 = meta_rows[lane * 2 + 1];
+      if (r1.x & 0x7FFFFFFFu) {
+        const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 20;
+        uint8_t* rec = B.out[m] + (((uint64_t)r0.w << 32) | r0.z);
+        if (hl <= 32u) {
+          const uint4* hrow = B.meta + ((size_t)m * B.n_slots + t) * 4 + 2;
+          const uint4 h0 = hrow[0], h1 = hrow[1];
+          uint8_t* q = rec;
+          uint32_t rem = hl;
+          uint4 part = h0;
+          if (hl >= 16u) { __builtin_memcpy(q, &h0, 16); q += 16; rem -= 16u; part = h1; }
+          if (rem == 16u) __builtin_memcpy(q, &part, 16);
+          else store_var(q, ((uint64_t)part.y << 32) | part.x, ((uint64_t)part.w << 32) | part.z, rem);
+        }
+        const uint4 tr = tail_rows[lane];
+        const uint32_t d = (tr.x != 0xFFFFFFFFu) ? (np & 7u) : 0u;  // bases (and qualities) of the partial item
+        const uint64_t S = ((uint64_t)tr.y << 32) | tr.x, Q = ((uint64_t)tr.w << 32) | tr.z;
+        const uint64_t keep = (1ull << (8u * d)) - 1ull;
+        uint8_t* so = rec + hl + (np - d);
+        // d bases + "\n+\n" (3..10 bytes), d qualities + '\n' (1..8 bytes)
+        const uint64_t s_lo = (S & keep) | (0x0A2B0Aull << (8u * d));
+        const uint64_t s_hi = d > 5u ? (0x0A2B0Aull >> (8u * (8u - d))) : 0ull;
+        store_var(so, s_lo, s_hi, d + 3u);
+        store_var(so + np + 3u, (Q & keep) | (0x0Aull << (8u * d)), 0ull, d + 1u);
       }
     }
     wave_lds_sync();
@@ -1197,7 +1206,7 @@ static EmitLds emit_lds(const DevProfile& P) {
   e.sub_rows = kmer_count * (uint32_t)P.bins;
   e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
   e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 * 16;
   const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
   const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
   e.sub_lds = fixed + sub_b <= kLdsBytes;

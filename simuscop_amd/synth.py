@@ -37,8 +37,9 @@ def _unit(h: np.ndarray) -> np.ndarray:
 
 
 def synth_contig(length: int, seed: int, contig_index: int = 0, n_runs: bool = True,
-                 softmask: bool = True, block: int = 10000) -> np.ndarray:
-    """Return the contig as a uint8 array of ASCII bases."""
+                 softmask: bool = True, block: int = 10000, n_islands=None) -> np.ndarray:
+    """Return the contig as a uint8 array of ASCII bases.  `n_islands=(period, width)` drops a short
+    run of N every `period` bases (assembly gaps): fragments then regularly run into non-ACGT bases."""
     with np.errstate(over="ignore"):
         base_key = _splitmix64(np.array([seed * 1000003 + contig_index * 7919 + 1], dtype=np.uint64))[0]
         nblk = (length + block - 1) // block
@@ -70,6 +71,10 @@ def synth_contig(length: int, seed: int, contig_index: int = 0, n_runs: bool = T
         out[length - tel:] = ord("N")
         cen = length // 3
         out[cen:cen + min(50000, length // 50)] = ord("N")
+    if n_islands:
+        period, width = n_islands
+        for s0 in range(period // 2, length - width, period):
+            out[s0:s0 + width] = ord("N")
     if softmask and length >= 5000:
         s = length // 2
         e = s + min(2000, length // 20)

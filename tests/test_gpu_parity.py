@@ -48,7 +48,7 @@ def _stat(stderr, key):
     return int(re.search(key + r"=(\d+)", stderr).group(1))
 
 
-@pytest.mark.parametrize("name", ["wgs_pe_variants", "wgs_se_hs2000"])
+@pytest.mark.parametrize("name", ["indel_rich_n_islands_pe"])
 def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
     """The straight-line emit kernel queues the items it cannot do (non-ACGT windows, >= 2 indels) for
     emit_slow_kernel; a queue too small makes the engine emit the batch again with the generic kernel.
