@@ -31,6 +31,7 @@ extern "C" {
 #define SG_ERR_HIP 2         /* HIP runtime error (no GPU, OOM, ...) */
 #define SG_ERR_UNSUPPORTED 3 /* profile shape outside the kernels' range (bases != 4, kmer > 6 ...) */
 #define SG_ERR_OVERFLOW 4    /* more than SG_MAX_EVENTS sequencing indels in one read             */
+#define SG_ERR_FORMAT 5      /* FASTA without fixed-width lines (sg_reference_commit): use the host parser */
 
 #define SG_MAX_EVENTS 8
 
@@ -83,6 +84,53 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* prof);
  * (Segment::getFragSequence :1085-1101 -> Genome::produceFragment, Genome.cpp:599-632): on a chain
  * that is a plain substring, clipped at the chain end.  Bytes are upper-case ASCII.             */
 int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chains, const uint64_t* lens);
+
+/* ---- reference ingest and haplotype assembly on the device ------------------ */
+/* Replaces the reference's per-segment FASTA reads (lib/fastahack/Fasta.cpp:304-334 through
+ * Segment.cpp:137) and its std::string haplotype editing (Segment::generateSegSequences,
+ * Segment.cpp:124-460) for callers that do not hold haplotype strings themselves:
+ *   sg_reference_begin / _chunk   stream the FASTA file, as it is on disk, to the device;
+ *   sg_reference_scan             offsets of the header lines ('>' at a line start), unordered;
+ *   sg_reference_commit           contigs -> resident base codes (newlines dropped by index
+ *                                 arithmetic, upper-cased as Segment.cpp:143); SG_ERR_FORMAT when a
+ *                                 contig's lines are not of one width (fall back to host parsing
+ *                                 and pass line_bases = line_width = length);
+ *   sg_build_haplotypes           chains of one (population, chromosome) = copies of reference
+ *                                 ranges and literal bases, then single-base patches; same device
+ *                                 state afterwards as sg_upload_haplotypes.                        */
+typedef struct sg_contig {
+  uint64_t raw_offset;  /* file offset of the contig's first base                              */
+  uint64_t length;      /* bases                                                               */
+  uint32_t line_bases;  /* bases per line (.fai LINEBASES)                                     */
+  uint32_t line_width;  /* bytes per line incl. the line break (.fai LINEWIDTH)                */
+} sg_contig;
+int sg_reference_begin(sg_ctx* ctx, uint64_t raw_bytes);
+/* asynchronous on the ctx's stream: `host` must stay unchanged until sg_sync() returns */
+int sg_reference_chunk(sg_ctx* ctx, uint64_t offset, const void* host, uint64_t bytes);
+int sg_sync(sg_ctx* ctx);
+/* bit 0 of *flags: the file has ';' comment lines (not handled by sg_reference_commit) */
+int sg_reference_scan(sg_ctx* ctx, uint64_t* header_offsets, uint32_t cap, uint32_t* n_found, uint32_t* flags);
+int sg_reference_commit(sg_ctx* ctx, const sg_contig* contigs, uint32_t n_contigs);
+
+typedef struct sg_hap_piece {
+  uint64_t dst;     /* offset in chain `chain`                                                   */
+  uint64_t src;     /* kind 0: 0-based position on contig `contig`; kind 1: offset into literals */
+  uint32_t len;
+  uint32_t chain;
+  uint32_t contig;
+  uint32_t kind;
+} sg_hap_piece;
+typedef struct sg_hap_patch {
+  uint64_t dst;     /* offset in chain `chain` */
+  uint32_t chain;
+  uint32_t base;    /* ASCII, any case         */
+} sg_hap_patch;
+/* Pieces must tile every chain exactly (no byte of [0, lens[c]) left out); patches apply afterwards. */
+int sg_build_haplotypes(sg_ctx* ctx, int32_t n_chains, const uint64_t* lens, const sg_hap_piece* pieces, uint64_t n_pieces,
+                        const char* literals, uint64_t n_literal_bytes, const sg_hap_patch* patches, uint64_t n_patches);
+/* Diagnostic read-back of the resident chains (either upload route): base codes A0 C1 T2 G3, 'N' = 4,
+ * any other character = 5.                                                                        */
+int sg_haplotype_codes(sg_ctx* ctx, uint32_t chain, uint64_t offset, uint64_t n, uint8_t* codes_out);
 
 /* ---- sampling plan ------------------------------------------------------------------------ */
 /* One entry per sampling window of every processed segment (Segment.cpp:675 skips segments with no

@@ -21,7 +21,8 @@ SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit"]
 # every symbol include/simuscop_amd.h declares
 ENGINE_SYMBOLS = [
     "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
-    "sg_upload_haplotypes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
+    "sg_upload_haplotypes", "sg_reference_begin", "sg_reference_chunk", "sg_sync", "sg_reference_scan",
+    "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_host_free",
 ]
@@ -54,10 +55,23 @@ class SgGcWindow(C.Structure):
     _fields_ = [("start", C.c_uint64), ("chain", C.c_uint32), ("len", C.c_uint32)]
 
 
+class SgContig(C.Structure):
+    _fields_ = [("raw_offset", C.c_uint64), ("length", C.c_uint64), ("line_bases", C.c_uint32), ("line_width", C.c_uint32)]
+
+
+class SgHapPiece(C.Structure):
+    _fields_ = [("dst", C.c_uint64), ("src", C.c_uint64), ("len", C.c_uint32), ("chain", C.c_uint32),
+                ("contig", C.c_uint32), ("kind", C.c_uint32)]
+
+
+class SgHapPatch(C.Structure):
+    _fields_ = [("dst", C.c_uint64), ("chain", C.c_uint32), ("base", C.c_uint32)]
+
+
 class SimuOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("has_seed", C.c_int32), ("seed", C.c_uint64), ("write_files", C.c_int32),
                 ("fetch", C.c_int32), ("quiet", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32)]
+                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32)]
 
 
 class SimuStats(C.Structure):
@@ -92,6 +106,14 @@ def load_engine():
     lib.sg_set_seed.argtypes = [vp, C.c_uint64]
     lib.sg_load_profile.argtypes = [vp, C.POINTER(SgProfileCdf)]
     lib.sg_upload_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.sg_reference_begin.argtypes = [vp, C.c_uint64]
+    lib.sg_reference_chunk.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64]
+    lib.sg_sync.argtypes = [vp]
+    lib.sg_reference_scan.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.sg_reference_commit.argtypes = [vp, C.POINTER(SgContig), C.c_uint32]
+    lib.sg_build_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(SgHapPiece), C.c_uint64,
+                                        C.c_char_p, C.c_uint64, C.POINTER(SgHapPatch), C.c_uint64]
+    lib.sg_haplotype_codes.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p]
     lib.sg_plan.argtypes = [vp, C.POINTER(SgBatch)]
     lib.sg_sample.argtypes = [vp]
     lib.sg_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

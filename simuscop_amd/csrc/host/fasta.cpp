@@ -1,15 +1,22 @@
 // host/fasta.cpp -- see fasta.h.
 #include "fasta.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
+#include "../../../include/simuscop_amd.h"
 #include "common.h"
 
 namespace simu {
 
-void Fasta::open(const std::string& ref_file) {
+static std::string plain_path(const std::string& ref_file) {
   std::string path = ref_file;
   if (path.empty()) throw Error("genome sequence file not specified!");
   if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
@@ -19,6 +26,211 @@ void Fasta::open(const std::string& ref_file) {
     if (system(cmd.c_str()) != 0) throw Error("could not decompress " + path);
     path = plain;
   }
+  return path;
+}
+
+static std::string header_key(const std::string& header) {  // Fasta.cpp:58-69
+  size_t b = header.find_first_not_of(" \t");
+  std::string tok;
+  if (b != std::string::npos) {
+    size_t e = header.find_first_of(" \t\r", b);
+    tok = header.substr(b, e == std::string::npos ? std::string::npos : e - b);
+  }
+  return abbr_of_chr(tok);
+}
+
+namespace {
+struct EngineError {};
+void eng_check(sg_ctx* ctx, int rc, const char* what) {
+  if (rc != SG_OK) throw Error(std::string("GPU engine error in ") + what + ": " + sg_last_error(ctx));
+}
+// pread of [off, off+n) split over `threads` readers
+void parallel_pread(int fd, uint8_t* dst, uint64_t off, uint64_t n, int threads) {
+  auto one = [&](uint64_t a, uint64_t b) {
+    while (a < b) {
+      ssize_t got = pread(fd, dst + (a - off), b - a, (off_t)a);
+      if (got <= 0) throw Error("could not read the genome sequence file");
+      a += (uint64_t)got;
+    }
+  };
+  const uint64_t kMin = 4u << 20;
+  int t = (int)std::min<uint64_t>((uint64_t)std::max(1, threads), (n + kMin - 1) / kMin);
+  if (t <= 1) { one(off, off + n); return; }
+  std::vector<std::thread> pool;
+  std::vector<std::string> errs((size_t)t);
+  const uint64_t per = (n + t - 1) / t;
+  for (int i = 0; i < t; i++)
+    pool.emplace_back([&, i]() {
+      try { one(off + std::min<uint64_t>(n, per * i), off + std::min<uint64_t>(n, per * (i + 1))); }
+      catch (const std::exception& e) { errs[(size_t)i] = e.what(); }
+    });
+  for (std::thread& th : pool) th.join();
+  for (const std::string& e : errs)
+    if (!e.empty()) throw Error(e);
+}
+std::string pread_string(int fd, uint64_t off, uint64_t n) {
+  std::string s((size_t)n, '\0');
+  uint64_t have = 0;
+  while (have < n) {
+    ssize_t got = pread(fd, &s[have], n - have, (off_t)(off + have));
+    if (got <= 0) break;
+    have += (uint64_t)got;
+  }
+  s.resize((size_t)have);
+  return s;
+}
+}  // namespace
+
+void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads) {
+  const std::string path = plain_path(ref_file);
+  on_device = true;
+  names.clear(); seqs.clear(); contigs.clear(); contig_of.clear();
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw Error("could not open " + path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { ::close(fd); throw Error("could not open " + path); }
+  const uint64_t size = (uint64_t)sb.st_size;
+  bool ok = false;
+  void* stage[2] = {nullptr, nullptr};
+  try {
+    // ---- 1. stream the file image to HBM: reader threads fill one pinned buffer while the other copies
+    eng_check(ctx, sg_reference_begin(ctx, size), "sg_reference_begin");
+    const uint64_t kChunk = 64u << 20;
+    for (int i = 0; i < 2 && size; i++) {
+      eng_check(ctx, sg_host_alloc(ctx, std::min<uint64_t>(kChunk, size), &stage[i]), "sg_host_alloc");
+    }
+    int cur = 0;
+    for (uint64_t off = 0; off < size; off += kChunk, cur ^= 1) {
+      const uint64_t n = std::min<uint64_t>(kChunk, size - off);
+      parallel_pread(fd, (uint8_t*)stage[cur], off, n, threads);  // overlaps the copy of the other buffer
+      eng_check(ctx, sg_sync(ctx), "sg_sync");                    // the other buffer's copy is done: it is free next round
+      eng_check(ctx, sg_reference_chunk(ctx, off, stage[cur], n), "sg_reference_chunk");
+    }
+    eng_check(ctx, sg_sync(ctx), "sg_sync");
+    // ---- 2. header offsets from the device scan; header text and line shape from a few small preads
+    std::vector<uint64_t> hdr(1u << 16);
+    uint32_t found = 0, flags = 0;
+    eng_check(ctx, sg_reference_scan(ctx, hdr.data(), (uint32_t)hdr.size(), &found, &flags), "sg_reference_scan");
+    if (found > hdr.size()) {
+      hdr.resize(found);
+      eng_check(ctx, sg_reference_scan(ctx, hdr.data(), (uint32_t)hdr.size(), &found, &flags), "sg_reference_scan");
+    }
+    hdr.resize(found);
+    std::sort(hdr.begin(), hdr.end());
+    bool uniform = !(flags & 1u) && found > 0;
+    std::vector<std::string> keys;
+    std::vector<FastaContig> rows;
+    for (size_t i = 0; i < hdr.size() && uniform; i++) {
+      const uint64_t region_end = i + 1 < hdr.size() ? hdr[i + 1] : size;
+      // header line
+      std::string head;
+      uint64_t p = hdr[i] + 1, first = region_end;
+      for (;;) {
+        const std::string blk = pread_string(fd, p, std::min<uint64_t>(4096, region_end - p));
+        if (blk.empty()) break;
+        const size_t nl = blk.find('\n');
+        if (nl != std::string::npos) { head.append(blk, 0, nl); first = p + nl + 1; break; }
+        head += blk;
+        p += blk.size();
+      }
+      FastaContig row;
+      row.raw_offset = first;
+      // trailing line breaks (and blank lines) of the region do not belong to a line
+      uint64_t end = region_end;
+      while (end > first) {
+        const uint64_t n = std::min<uint64_t>(64, end - first);
+        const std::string tail = pread_string(fd, end - n, n);
+        size_t k = tail.size();
+        while (k > 0 && (tail[k - 1] == '\n' || tail[k - 1] == '\r')) k--;
+        end -= tail.size() - k;
+        if (k > 0) break;
+      }
+      const uint64_t body = end - first;
+      if (body) {
+        // first line: bases per line, bytes per line
+        uint64_t q = first, lb = body, lw = body;
+        bool found_nl = false;
+        while (q < end && !found_nl) {
+          const std::string blk = pread_string(fd, q, std::min<uint64_t>(1u << 16, end - q));
+          if (blk.empty()) break;
+          const size_t nl = blk.find('\n');
+          if (nl != std::string::npos) {
+            const uint64_t at = q + nl;  // file offset of the '\n'
+            const bool cr = at > first && (nl > 0 ? blk[nl - 1] == '\r' : pread_string(fd, at - 1, 1) == "\r");
+            lb = at - first - (cr ? 1 : 0);
+            lw = at - first + 1;
+            found_nl = true;
+          }
+          q += blk.size();
+        }
+        if (lb == 0 || lb > 0xFFFFFFF0ull || lw > 0xFFFFFFF0ull) { uniform = false; break; }
+        const uint64_t k = body / lw, r = body % lw;
+        if (r > lb) { uniform = false; break; }
+        row.length = k * lb + r;
+        row.line_bases = (uint32_t)lb;
+        row.line_width = (uint32_t)lw;
+      } else {
+        row.line_bases = row.line_width = 1;
+      }
+      keys.push_back(header_key(head));
+      rows.push_back(row);
+    }
+    if (uniform) {
+      std::vector<sg_contig> tab;
+      for (const FastaContig& r : rows) tab.push_back(sg_contig{r.raw_offset, r.length, r.line_bases, r.line_width});
+      const int rc = sg_reference_commit(ctx, tab.data(), (uint32_t)tab.size());
+      if (rc == SG_ERR_FORMAT) uniform = false;
+      else eng_check(ctx, rc, "sg_reference_commit");
+    }
+    if (uniform) {
+      contigs = rows;
+      for (size_t i = 0; i < keys.size(); i++) {  // a repeated name keeps its first place and its last sequence
+        if (!contig_of.count(keys[i])) names.push_back(keys[i]);
+        contig_of[keys[i]] = (uint32_t)i;
+      }
+      streamed = true;
+      ok = true;
+    }
+  } catch (...) {
+    ::close(fd);
+    for (void* b : stage) if (b) sg_host_free(ctx, b);
+    throw;
+  }
+  ::close(fd);
+  for (void* b : stage) if (b) sg_host_free(ctx, b);
+  if (!ok) {
+    // ---- general parser on the host, result uploaded as one line per contig
+    open(ref_file);
+    on_device = true;
+    streamed = false;
+    uint64_t total = 0;
+    std::vector<sg_contig> tab;
+    for (const std::string& k : names) {
+      const std::string& s = seqs.at(k);
+      contig_of[k] = (uint32_t)contigs.size();
+      FastaContig row;
+      row.raw_offset = total; row.length = s.size();
+      row.line_bases = row.line_width = (uint32_t)std::max<size_t>(1, std::min<size_t>(s.size(), 0xFFFFFFF0u));
+      if (s.size() > 0xFFFFFFF0ull) throw Error("ERROR: contig " + k + " is longer than 4 Gbp");
+      contigs.push_back(row);
+      tab.push_back(sg_contig{row.raw_offset, row.length, row.line_bases, row.line_width});
+      total += s.size();
+    }
+    eng_check(ctx, sg_reference_begin(ctx, total), "sg_reference_begin");
+    for (const std::string& k : names) {
+      const std::string& s = seqs.at(k);
+      eng_check(ctx, sg_reference_chunk(ctx, contigs[contig_of[k]].raw_offset, s.data(), s.size()), "sg_reference_chunk");
+    }
+    eng_check(ctx, sg_sync(ctx), "sg_sync");
+    eng_check(ctx, sg_reference_commit(ctx, tab.data(), (uint32_t)tab.size()), "sg_reference_commit");
+    seqs.clear();
+  }
+  if (names.empty()) throw Error("ERROR: reference sequence cannot be empty!");
+}
+
+void Fasta::open(const std::string& ref_file) {
+  const std::string path = plain_path(ref_file);
+  on_device = false;
   FILE* fp = fopen(path.c_str(), "rb");
   if (!fp) throw Error("could not open " + path);
   names.clear();
@@ -39,13 +251,7 @@ void Fasta::open(const std::string& ref_file) {
         p = nl + 1;
         if (in_header) {
           in_header = false;
-          size_t b = header.find_first_not_of(" \t");
-          std::string tok;
-          if (b != std::string::npos) {
-            size_t e = header.find_first_of(" \t", b);
-            tok = header.substr(b, e == std::string::npos ? std::string::npos : e - b);
-          }
-          std::string key = abbr_of_chr(tok);
+          std::string key = header_key(header);
           if (!seqs.count(key)) names.push_back(key);
           cur = &seqs[key];
           cur->clear();
@@ -61,6 +267,7 @@ void Fasta::open(const std::string& ref_file) {
       }
       const char* nl = (const char*)memchr(p, '\n', end - p);
       const char* stop = nl ? nl : end;
+      if (nl && stop > p && stop[-1] == '\r') stop--;  // CRLF files: the index arithmetic (LINEBASES) excludes it too
       if (cur && stop > p) {
         size_t old = cur->size();
         cur->append(p, stop - p);

@@ -249,11 +249,176 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
       if (c >= 'a' && c <= 'z') c -= 32;  // variant alleles may be lower-case in the input (Segment.cpp:456)
 }
 
+// The same edits as segment_haplotypes(), kept as a piece table instead of bytes: every operation the
+// reference applies to its std::strings (Segment.cpp:210-447) is an index operation -- assign at i,
+// insert at i, erase [i, i+n) -- so the string's final content is a list of ranges of the replicated
+// reference slice S0 (copy t of the slice at [t*ref_size, (t+1)*ref_size)) and of inserted literals.
+// The substitutions all happen before the first length change, so they are positions of S0 and are
+// carried through the table at the end.
+void Genome::segment_pieces(const std::string& popu, const std::string& chr, Segment& g, ChromPlan& plan) {
+  const int ploidy = cfg.ploidy();
+  const uint32_t contig = fa.contig_of.at(chr);
+  // contig.substr(start-1, ref_size) clips at the contig end
+  const unsigned ref_size = (unsigned)std::min<long>((long)g.ref_size(), fa.length(chr) - (g.start - 1));
+  struct Piece { uint32_t kind; uint64_t src; uint64_t len; };
+  auto major = [&](int h) { return std::find(g.m_indx.begin(), g.m_indx.end(), h) != g.m_indx.end(); };
+  auto carries = [&](int h, bool homo, int parity) { return homo || (parity == 0) == major(h); };
+
+  std::vector<std::vector<Piece>> table((size_t)ploidy);
+  std::vector<uint64_t> size((size_t)ploidy, 0);
+  std::vector<std::map<uint64_t, char>> subs((size_t)ploidy);  // S0 index -> allele (a later one replaces an earlier one)
+  std::vector<unsigned> copies0((size_t)ploidy, 0);
+  for (int h = 0; h < ploidy; h++) {
+    int reps;
+    if (g.cn < ploidy) reps = std::find(g.seq_reps.begin(), g.seq_reps.end(), h) != g.seq_reps.end() ? 1 : 0;
+    else reps = g.seq_reps[h];
+    copies0[h] = (unsigned)reps;
+    size[h] = (uint64_t)reps * ref_size;
+    if (size[h]) table[h].push_back(Piece{0, 0, size[h]});
+  }
+  auto substitute = [&](int h, int sindx, char c) {
+    for (unsigned t = 0; t < copies0[h]; t++) subs[h][(uint64_t)sindx + (uint64_t)t * ref_size] = c;
+  };
+  int parity = 0;
+  for (const SNP& snp : lookup(snps, chr)) {
+    if (snp.pos < g.start || snp.pos > g.end) continue;
+    for (int h = 0; h < ploidy; h++)
+      if (carries(h, false, parity)) substitute(h, (int)(snp.pos - g.start), snp.nucleotide);
+    parity ^= 1;
+  }
+  parity = 0;
+  for (const SNV& v : lookup2(snvs, popu, chr)) {
+    if (v.pos < g.start || v.pos > g.end) continue;
+    const bool homo = v.type == HOMO;
+    for (int h = 0; h < ploidy; h++)
+      if (carries(h, homo, parity)) substitute(h, (int)(v.pos - g.start), v.alt);
+    if (!homo) parity ^= 1;
+  }
+  // piece-table forms of std::string::insert / erase
+  auto split_at = [](std::vector<Piece>& tb, uint64_t at) -> size_t {  // index of the piece starting at `at`
+    uint64_t pos = 0;
+    for (size_t i = 0; i < tb.size(); i++) {
+      if (pos == at) return i;
+      if (at < pos + tb[i].len) {
+        const uint64_t left = at - pos;
+        Piece right{tb[i].kind, tb[i].src + left, tb[i].len - left};
+        tb[i].len = left;
+        tb.insert(tb.begin() + (long)i + 1, right);
+        return i + 1;
+      }
+      pos += tb[i].len;
+    }
+    return tb.size();
+  };
+  auto insert_lit = [&](int h, uint64_t at, uint64_t lit_off, uint64_t len) {
+    if (at > size[h]) throw Error("ERROR: insertion falls outside its haplotype on chromosome " + chr);
+    if (!len) return;
+    const size_t i = split_at(table[h], at);
+    table[h].insert(table[h].begin() + (long)i, Piece{1, lit_off, len});
+    size[h] += len;
+  };
+  auto erase = [&](int h, uint64_t at, uint64_t len) {
+    len = std::min(len, size[h] - at);  // std::string::erase clamps
+    if (!len) return;
+    const size_t a = split_at(table[h], at), b = split_at(table[h], at + len);
+    table[h].erase(table[h].begin() + (long)a, table[h].begin() + (long)b);
+    size[h] -= len;
+  };
+
+  std::vector<std::map<int, int>> ins_at(ploidy), del_at(ploidy);
+  std::vector<int> ins_total(ploidy, 0), del_total(ploidy, 0);
+  auto shift = [](const std::map<int, int>& m, int sindx) {
+    int s = 0;
+    for (auto& kv : m) {
+      if (kv.first > sindx) break;
+      s += kv.second;
+    }
+    return s;
+  };
+  parity = 0;
+  for (const Insertion& ins : lookup2(inserts, popu, chr)) {
+    if (ins.pos < g.start || ins.pos > g.end) continue;
+    const bool homo = ins.type == HOMO;
+    const int sindx = (int)(ins.pos + 1 - g.start);
+    const int len = (int)ins.seq.size();
+    uint64_t lit_off = ~0ull;
+    for (int h = 0; h < ploidy; h++) {
+      if (!carries(h, homo, parity)) continue;
+      if (lit_off == ~0ull) { lit_off = plan.literals.size(); plan.literals += ins.seq; }
+      const int offset = shift(ins_at[h], sindx);
+      const int unit = (int)ref_size + ins_total[h];
+      const int copies = (int)(size[h] / (uint64_t)unit);
+      for (int t = 0; t < copies; t++) insert_lit(h, (uint64_t)((long)sindx + offset + (long)t * (unit + len)), lit_off, (uint64_t)len);
+      ins_total[h] += len;
+      ins_at[h].insert(std::make_pair(sindx, len));
+    }
+    if (!homo) parity ^= 1;
+  }
+  parity = 0;
+  for (const Deletion& d : lookup2(dels, popu, chr)) {
+    if (d.pos < g.start || d.pos > g.end) continue;
+    const bool homo = d.type == HOMO;
+    const int sindx = (int)(d.pos - g.start);
+    for (int h = 0; h < ploidy; h++) {
+      if (!carries(h, homo, parity)) continue;
+      const int offset = shift(ins_at[h], sindx) - shift(del_at[h], sindx);
+      if (sindx + offset < 0) continue;
+      const int unit = (int)ref_size + ins_total[h] - del_total[h];
+      const int copies = (int)(size[h] / (uint64_t)unit);
+      for (int t = 0; t < copies; t++) {
+        const uint64_t at = (uint64_t)((long)sindx + offset + (long)t * (unit - d.length));
+        if (at > size[h]) throw Error("ERROR: deletion at " + std::to_string(d.pos) + " falls outside its haplotype");
+        erase(h, at, (uint64_t)d.length);
+      }
+      del_total[h] += d.length;
+      del_at[h].insert(std::make_pair(sindx, d.length));
+    }
+    if (!homo) parity ^= 1;
+  }
+
+  // flatten: destination offsets, S0 ranges cut at copy boundaries -> contig coordinates
+  for (int h = 0; h < ploidy; h++) {
+    g.hap_base[h] = plan.chain_len[h];
+    g.hap_len[h] = size[h];
+    uint64_t dst = plan.chain_len[h];
+    std::vector<std::pair<uint64_t, uint64_t>> s0_at;  // (S0 start of a kind-0 piece, its dst), ascending in both
+    std::vector<uint64_t> s0_len;
+    for (const Piece& p : table[h]) {
+      if (p.kind == 1) {
+        for (uint64_t o = 0; o < p.len; o += 0x40000000ull)
+          plan.pieces.push_back(sg_hap_piece{dst + o, p.src + o, (uint32_t)std::min<uint64_t>(0x40000000ull, p.len - o), (uint32_t)h, 0, 1});
+      } else {
+        s0_at.emplace_back(p.src, dst);
+        s0_len.push_back(p.len);
+        uint64_t o = 0;
+        while (o < p.len) {
+          const uint64_t s0 = p.src + o, in_copy = s0 % ref_size;
+          const uint64_t n = std::min<uint64_t>(p.len - o, ref_size - in_copy);
+          plan.pieces.push_back(sg_hap_piece{dst + o, (uint64_t)(g.start - 1) + in_copy, (uint32_t)n, (uint32_t)h, contig, 0});
+          o += n;
+        }
+      }
+      dst += p.len;
+    }
+    plan.chain_len[h] = dst;
+    for (const auto& kv : subs[h]) {  // a substituted base that was deleted afterwards is in no piece
+      auto it = std::upper_bound(s0_at.begin(), s0_at.end(), std::pair<uint64_t, uint64_t>(kv.first, ~(uint64_t)0));
+      if (it == s0_at.begin()) continue;
+      --it;
+      const size_t i = (size_t)(it - s0_at.begin());
+      if (kv.first >= it->first + s0_len[i]) continue;
+      plan.patches.push_back(sg_hap_patch{it->second + (kv.first - it->first), (uint32_t)h, (uint32_t)(uint8_t)kv.second});
+    }
+  }
+}
+
 void Genome::build_chains(const std::string& popu, const std::string& chr, uint64_t seed) {
   ChromPlan& plan = plans.at(popu).at(chr);
   if (plan.chains_built) return;
   const int ploidy = cfg.ploidy();
-  plan.chains.assign(ploidy, std::string());
+  plan.chains.assign(device_haps ? 0 : ploidy, std::string());
+  plan.chain_len.assign(ploidy, 0);
+  plan.pieces.clear(); plan.patches.clear(); plan.literals.clear();
   const uint32_t ctx = host_ctx(popu, chr);
   const long clen = fa.length(chr);
   std::vector<std::string> haps;
@@ -264,11 +429,16 @@ void Genome::build_chains(const std::string& popu, const std::string& chr, uint6
     g.has_seq = false;
     if (g.cn == 0 || clen < g.start) continue;  // Segment.cpp:131-141
     choose_haplotypes(g, seed, ctx, (uint32_t)k);
-    segment_haplotypes(popu, chr, g, haps);
-    for (int h = 0; h < ploidy; h++) {
-      g.hap_base[h] = plan.chains[h].size();
-      g.hap_len[h] = haps[h].size();
-      plan.chains[h] += haps[h];
+    if (device_haps) {
+      segment_pieces(popu, chr, g, plan);
+    } else {
+      segment_haplotypes(popu, chr, g, haps);
+      for (int h = 0; h < ploidy; h++) {
+        g.hap_base[h] = plan.chains[h].size();
+        g.hap_len[h] = haps[h].size();
+        plan.chains[h] += haps[h];
+        plan.chain_len[h] = plan.chains[h].size();
+      }
     }
     g.has_seq = true;
   }

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/simuscop_amd.h"
 #include "config.h"
 #include "fasta.h"
 #include "profile.h"
@@ -50,7 +51,12 @@ struct Segment {
 
 struct ChromPlan {  // one (population, chromosome)
   std::vector<Segment> segs;
-  std::vector<std::string> chains;  // [ploidy]
+  std::vector<std::string> chains;  // [ploidy]  (host haplotypes only)
+  // device haplotypes: the chains as copy lists for sg_build_haplotypes
+  std::vector<uint64_t> chain_len;
+  std::vector<sg_hap_piece> pieces;
+  std::vector<sg_hap_patch> patches;
+  std::string literals;
   bool chains_built = false, windows_built = false, weighed = false;
   std::vector<uint32_t> w_spos, w_len, w_hap;  // Segment::fragStartPos / (End-Start+1) / hapIndxs
   std::vector<double> w_weight;                // Segment::fragWeights
@@ -71,6 +77,11 @@ struct Genome {
   std::map<std::string, std::vector<Target>> targets;  // after divide_targets
   std::vector<std::vector<float>> mix_props;
   std::map<std::string, std::map<std::string, ChromPlan>> plans;  // [popu][chr]
+
+  // true: the reference lives on the device (Fasta::open_on_device) and build_chains() writes copy
+  // lists instead of strings
+  bool device_haps = false;
+  ::sg_ctx* engine = nullptr;
 
   explicit Genome(Config& c) : cfg(c) {}
 
@@ -99,6 +110,7 @@ struct Genome {
   void divide_segment(std::vector<Segment>& out, const std::string& chr, long s, long e, int cn, int mcn, int& idx);
   void choose_haplotypes(Segment& g, uint64_t seed, uint32_t ctx24, uint32_t seg_ord);
   void segment_haplotypes(const std::string& popu, const std::string& chr, Segment& g, std::vector<std::string>& out);
+  void segment_pieces(const std::string& popu, const std::string& chr, Segment& g, ChromPlan& plan);
 };
 
 }  // namespace simu

@@ -1,6 +1,6 @@
 // host/main.cpp -- `simuReads <configuration file>` (src/simuReads.cpp:24-97), GPU-backed.
 // Same positional argument, usage text and exit codes; optional flags are additive:
-//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats
+//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +41,7 @@ int main(int argc, char* argv[]) {
     else if (a == "--rank") opt.shard_rank = atoi(val());
     else if (a == "--world") opt.shard_world = atoi(val());
     else if (a == "--stats") stats = true;
+    else if (a == "--host-haplotypes") opt.host_haplotypes = 1;
     else if (config.empty()) config = a;
     else {
       std::cerr << "Error: too many input arguments!" << std::endl;

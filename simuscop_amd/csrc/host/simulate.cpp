@@ -91,10 +91,17 @@ struct Driver {
     const std::string key = popu + "\t" + chr;
     if (resident == key) return;
     ChromPlan& plan = genome.plans[popu][chr];
-    std::vector<const char*> ptr;
-    std::vector<uint64_t> len;
-    for (const std::string& c : plan.chains) { ptr.push_back(c.data()); len.push_back(c.size()); }
-    eng.check(sg_upload_haplotypes(eng.ctx, (int32_t)ptr.size(), ptr.data(), len.data()), "sg_upload_haplotypes");
+    if (genome.device_haps) {
+      eng.check(sg_build_haplotypes(eng.ctx, (int32_t)plan.chain_len.size(), plan.chain_len.data(), plan.pieces.data(),
+                                    plan.pieces.size(), plan.literals.data(), plan.literals.size(), plan.patches.data(),
+                                    plan.patches.size()),
+                "sg_build_haplotypes");
+    } else {
+      std::vector<const char*> ptr;
+      std::vector<uint64_t> len;
+      for (const std::string& c : plan.chains) { ptr.push_back(c.data()); len.push_back(c.size()); }
+      eng.check(sg_upload_haplotypes(eng.ctx, (int32_t)ptr.size(), ptr.data(), len.data()), "sg_upload_haplotypes");
+    }
     resident = key;
   }
 
@@ -393,13 +400,15 @@ struct Driver {
     auto t0 = Clock::now();
     cfg.load(config_path);
     seed = opt.has_seed ? opt.seed : (uint64_t)cfg.num["seed"];
+    const int device = opt.device >= 0 ? opt.device : (int)cfg.num["device"];
+    if (sg_create(&eng.ctx, device, seed) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(nullptr));
+    sg_set_profiling(eng.ctx, 1);
+    genome.device_haps = !opt.host_haplotypes;
+    genome.engine = eng.ctx;
     genome.load_data();
     const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
     if (opt.write_files) mkdir(out_dir.c_str(), 0755);  // src/simuReads.cpp:56-60
     (void)out_dir;
-    const int device = opt.device >= 0 ? opt.device : (int)cfg.num["device"];
-    if (sg_create(&eng.ctx, device, seed) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(nullptr));
-    sg_set_profiling(eng.ctx, 1);
     prof.train(cfg.str["profile"], cfg.paired(), (int)cfg.num["insertSize"]);
     log("profile was loaded from file " + cfg.str["profile"] + "\n");
     sg_profile_cdf view = prof.view();

@@ -18,6 +18,9 @@ typedef struct simu_options {
   int32_t shard_world;     // 1 = no sharding
   const char* output_dir;  // NULL / "": use the config's `output`
   int32_t repeat_sample;   // >1: re-run sg_sample this many times per batch (kernel timing experiments)
+  int32_t host_haplotypes; // 1: parse the FASTA and edit haplotype strings on the host, upload them
+                           // (sg_upload_haplotypes); 0 (default): stream the file to the device and
+                           // assemble the haplotypes there (sg_reference_*, sg_build_haplotypes)
 } simu_options;
 
 typedef struct simu_stats {
@@ -27,7 +30,7 @@ typedef struct simu_stats {
   uint64_t planned_reads;  // Genome::yieldReads `reads` (Genome.cpp:831)
   uint64_t windows, segments, batches;
   double t_load;           // config + inputs + profile
-  double t_haplotypes;     // build chains (host)
+  double t_haplotypes;     // haplotype chains: edit lists or strings (host)
   double t_plan;           // GC scan (device) + weights + read counts (host)
   double t_sample;         // sg_plan + sg_sample + sg_result (GPU pass, wall)
   double t_fetch;          // D2H of FASTQ text

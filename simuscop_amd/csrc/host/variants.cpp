@@ -163,7 +163,8 @@ void Genome::load_abundance() {
 void Genome::load_data() {
   load_variations();
   load_snps();
-  fa.open(cfg.str["ref"]);
+  if (device_haps) fa.open_on_device(cfg.str["ref"], engine, (int)std::max<long long>(1, cfg.num["threads"]));
+  else fa.open(cfg.str["ref"]);
   chromosomes = fa.names;
   load_targets();
   divide_targets();

@@ -5,6 +5,7 @@
 // sequencing on one HIP stream.  There is no CPU fallback: without a HIP device sg_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,16 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
+// sg_haplotypes.hip
+struct DevContig { uint64_t raw_off, code_off, length; uint32_t line_bases, line_width; uint64_t first_block; };
+struct DevPiece { uint64_t dst, src; uint32_t len, pad; };
+struct DevPatch { uint64_t dst; uint32_t base, pad; };
+void launch_ref_scan(const uint8_t* raw, uint64_t n, uint64_t* list, uint32_t cap, uint32_t* count, uint32_t* flags, hipStream_t s);
+void launch_ref_ingest(const uint8_t* raw, uint8_t* codes, const void* contigs, uint32_t n_contigs, uint64_t n_blocks,
+                       uint32_t* flags, hipStream_t s);
+void launch_hap_copy(uint8_t* chains, const uint8_t* ref_codes, const uint8_t* literals, const void* pieces, uint64_t n, hipStream_t s);
+void launch_hap_patch(uint8_t* chains, const void* patches, uint64_t n, hipStream_t s);
+void launch_encode_bytes(uint8_t* buf, uint64_t n, hipStream_t s);
 }  // namespace sg
 
 namespace {
@@ -60,7 +71,9 @@ struct sg_ctx {
   sg::DevProfile P{};
   sg::DevBatch B{};
   DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
-      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq;
+      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work;
+  uint64_t ref_raw_bytes = 0;
+  std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
   uint64_t host_flags[2] = {0, 0};  // totals[3..4] after the emit kernels: flags, slow-queue counts
   uint64_t slow_items = 0;
@@ -125,7 +138,8 @@ void sg_destroy(sg_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
-                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq})
+                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq,
+                    &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work})
     b->release();
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
@@ -308,6 +322,177 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   }
   ctx->have_profile = true;
   ctx->have_plan = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference ingest + haplotype assembly on the device (kernels: sg_haplotypes.hip)
+// ------------------------------------------------------------------------------------------------
+int sg_reference_begin(sg_ctx* ctx, uint64_t raw_bytes) {
+  if (!ctx) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_ENSURE(ctx->ref_raw, raw_bytes + 64);
+  SG_HIP(hipMemsetAsync((uint8_t*)ctx->ref_raw.p + raw_bytes, '\n', 64, ctx->stream));  // the scan reads whole 16-byte words
+  ctx->ref_raw_bytes = raw_bytes;
+  ctx->ref_contigs.clear();
+  return SG_OK;
+}
+
+int sg_reference_chunk(sg_ctx* ctx, uint64_t offset, const void* host, uint64_t bytes) {
+  if (!ctx || (!host && bytes)) return SG_ERR_INVALID;
+  if (!ctx->ref_raw.p || offset + bytes > ctx->ref_raw_bytes) return ctx->fail(SG_ERR_INVALID, "sg_reference_chunk: range outside sg_reference_begin's size");
+  SG_HIP(hipSetDevice(ctx->device));
+  if (bytes) SG_HIP(hipMemcpyAsync((uint8_t*)ctx->ref_raw.p + offset, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return SG_OK;
+}
+
+int sg_sync(sg_ctx* ctx) {
+  if (!ctx) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  return SG_OK;
+}
+
+int sg_reference_scan(sg_ctx* ctx, uint64_t* header_offsets, uint32_t cap, uint32_t* n_found, uint32_t* flags) {
+  if (!ctx || !n_found || (cap && !header_offsets)) return SG_ERR_INVALID;
+  if (!ctx->ref_raw.p) return ctx->fail(SG_ERR_INVALID, "sg_reference_scan: call sg_reference_begin first");
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_ENSURE(ctx->hap_work, (size_t)cap * 8 + 64);
+  uint32_t* counters = (uint32_t*)((uint8_t*)ctx->hap_work.p + (size_t)cap * 8);
+  SG_HIP(hipMemsetAsync(counters, 0, 8, ctx->stream));
+  sg::launch_ref_scan(ctx->ref_raw.as<uint8_t>(), ctx->ref_raw_bytes, ctx->hap_work.as<uint64_t>(), cap, counters, counters + 1, ctx->stream);
+  SG_HIP(hipGetLastError());
+  uint32_t host_c[2] = {0, 0};
+  SG_HIP(hipMemcpyAsync(host_c, counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_found = host_c[0];
+  if (flags) *flags = host_c[1];
+  const uint32_t n = host_c[0] < cap ? host_c[0] : cap;
+  if (n) SG_HIP(hipMemcpy(header_offsets, ctx->hap_work.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return SG_OK;
+}
+
+int sg_reference_commit(sg_ctx* ctx, const sg_contig* contigs, uint32_t n_contigs) {
+  if (!ctx || (n_contigs && !contigs)) return SG_ERR_INVALID;
+  if (!ctx->ref_raw.p) return ctx->fail(SG_ERR_INVALID, "sg_reference_commit: call sg_reference_begin first");
+  SG_HIP(hipSetDevice(ctx->device));
+  std::vector<sg::DevContig> tab(n_contigs);
+  uint64_t code_off = 0, blocks = 0;
+  for (uint32_t c = 0; c < n_contigs; c++) {
+    const sg_contig& k = contigs[c];
+    if (k.length && (k.line_bases == 0 || k.line_width < k.line_bases))
+      return ctx->fail(SG_ERR_INVALID, "sg_reference_commit: contig " + std::to_string(c) + " has an impossible line shape");
+    const uint64_t lines = k.length ? (k.length - 1) / k.line_bases : 0;  // line breaks inside the contig
+    if (k.raw_offset + k.length + lines * (k.line_width - k.line_bases) > ctx->ref_raw_bytes)
+      return ctx->fail(SG_ERR_INVALID, "sg_reference_commit: contig " + std::to_string(c) + " runs past the end of the file");
+    tab[c] = sg::DevContig{k.raw_offset, code_off, k.length, k.line_bases, k.line_width, blocks};
+    blocks += (k.length + 15) / 16;
+    code_off += ((k.length + 15) / 16) * 16 + 64;
+  }
+  SG_ENSURE(ctx->ref_codes, code_off + 64);
+  SG_ENSURE(ctx->ref_meta, (size_t)n_contigs * sizeof(sg::DevContig) + 64);
+  uint32_t* flags = (uint32_t*)((uint8_t*)ctx->ref_meta.p + (size_t)n_contigs * sizeof(sg::DevContig));
+  SG_HIP(hipMemsetAsync(flags, 0, 4, ctx->stream));
+  if (n_contigs) SG_HIP(hipMemcpyAsync(ctx->ref_meta.p, tab.data(), (size_t)n_contigs * sizeof(sg::DevContig), hipMemcpyHostToDevice, ctx->stream));
+  sg::launch_ref_ingest(ctx->ref_raw.as<uint8_t>(), ctx->ref_codes.as<uint8_t>(), ctx->ref_meta.p, n_contigs, blocks, flags, ctx->stream);
+  SG_HIP(hipGetLastError());
+  uint32_t host_flags = 0;
+  SG_HIP(hipMemcpyAsync(&host_flags, flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  if (host_flags & 2u) return ctx->fail(SG_ERR_FORMAT, "sg_reference_commit: a contig's lines are not of one width");
+  ctx->ref_contigs = tab;
+  ctx->ref_raw.release();  // the file image is not needed again
+  ctx->ref_raw_bytes = 0;
+  return SG_OK;
+}
+
+int sg_build_haplotypes(sg_ctx* ctx, int32_t n_chains, const uint64_t* lens, const sg_hap_piece* pieces, uint64_t n_pieces,
+                        const char* literals, uint64_t n_literal_bytes, const sg_hap_patch* patches, uint64_t n_patches) {
+  if (!ctx || n_chains < 0 || (n_chains && !lens) || (n_pieces && !pieces) || (n_patches && !patches) ||
+      (n_literal_bytes && !literals))
+    return SG_ERR_INVALID;
+  if (ctx->ref_contigs.empty() && n_pieces) return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: call sg_reference_commit first");
+  SG_HIP(hipSetDevice(ctx->device));
+  const size_t PAD = 256;  // same layout as sg_upload_haplotypes
+  std::vector<uint64_t> meta(2 * (size_t)n_chains + 2, 0);
+  size_t total = PAD;
+  for (int c = 0; c < n_chains; c++) {
+    meta[c] = total;
+    meta[n_chains + c] = lens[c];
+    total += (lens[c] + PAD + 63) & ~(size_t)63;
+  }
+  total += PAD;
+  total = (total + 15) & ~(size_t)15;
+  // absolute offsets, long pieces split so that every workgroup moves <= 64 KB; coverage is checked
+  // by summing the piece lengths per chain after a bounds check of each piece
+  const uint32_t kSplit = 1u << 16;
+  std::vector<sg::DevPiece> dp;
+  dp.reserve((size_t)n_pieces + total / kSplit + 16);
+  std::vector<uint64_t> covered((size_t)n_chains, 0);
+  for (uint64_t i = 0; i < n_pieces; i++) {
+    const sg_hap_piece& p = pieces[i];
+    if ((int64_t)p.chain >= n_chains || p.dst + p.len > lens[p.chain])
+      return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: piece " + std::to_string(i) + " falls outside its chain");
+    uint64_t src;
+    if (p.kind == 0) {
+      if (p.contig >= ctx->ref_contigs.size() || p.src + p.len > ctx->ref_contigs[p.contig].length)
+        return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: piece " + std::to_string(i) + " falls outside its contig");
+      src = ctx->ref_contigs[p.contig].code_off + p.src;
+    } else {
+      if (p.src + p.len > n_literal_bytes)
+        return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: piece " + std::to_string(i) + " falls outside the literal bytes");
+      src = p.src;
+    }
+    covered[p.chain] += p.len;
+    for (uint32_t o = 0; o < p.len; o += kSplit)
+      dp.push_back(sg::DevPiece{meta[p.chain] + p.dst + o, src + o, std::min<uint32_t>(kSplit, p.len - o), p.kind ? 1u : 0u});
+  }
+  for (int c = 0; c < n_chains; c++)
+    if (covered[c] != lens[c]) return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: the pieces of chain " + std::to_string(c) + " do not add up to its length");
+  std::vector<sg::DevPatch> pt((size_t)n_patches);
+  for (uint64_t i = 0; i < n_patches; i++) {
+    const sg_hap_patch& q = patches[i];
+    if ((int64_t)q.chain >= n_chains || q.dst >= lens[q.chain])
+      return ctx->fail(SG_ERR_INVALID, "sg_build_haplotypes: patch " + std::to_string(i) + " falls outside its chain");
+    pt[i] = sg::DevPatch{meta[q.chain] + q.dst, q.base, 0};
+  }
+  SG_ENSURE(ctx->chains, total);
+  SG_ENSURE(ctx->chain_meta, meta.size() * 8);
+  const size_t pieces_b = (dp.size() * sizeof(sg::DevPiece) + 63) & ~(size_t)63, patches_b = (pt.size() * sizeof(sg::DevPatch) + 63) & ~(size_t)63;
+  SG_ENSURE(ctx->hap_work, pieces_b + patches_b + n_literal_bytes + 64);
+  uint8_t* wk = ctx->hap_work.as<uint8_t>();
+  SG_HIP(hipMemsetAsync(ctx->chains.p, 4, total, ctx->stream));  // guard bytes read as 'N'
+  if (!dp.empty()) SG_HIP(hipMemcpyAsync(wk, dp.data(), dp.size() * sizeof(sg::DevPiece), hipMemcpyHostToDevice, ctx->stream));
+  if (!pt.empty()) SG_HIP(hipMemcpyAsync(wk + pieces_b, pt.data(), pt.size() * sizeof(sg::DevPatch), hipMemcpyHostToDevice, ctx->stream));
+  if (n_literal_bytes) {
+    SG_HIP(hipMemcpyAsync(wk + pieces_b + patches_b, literals, n_literal_bytes, hipMemcpyHostToDevice, ctx->stream));
+    sg::launch_encode_bytes(wk + pieces_b + patches_b, n_literal_bytes, ctx->stream);
+  }
+  SG_HIP(hipMemcpyAsync(ctx->chain_meta.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  sg::launch_hap_copy(ctx->chains.as<uint8_t>(), ctx->ref_codes.as<uint8_t>(), wk + pieces_b + patches_b, wk, dp.size(), ctx->stream);
+  sg::launch_hap_patch(ctx->chains.as<uint8_t>(), wk + pieces_b, pt.size(), ctx->stream);
+  SG_HIP(hipGetLastError());
+  SG_HIP(hipStreamSynchronize(ctx->stream));  // dp / pt / meta are stack-owned host memory
+  ctx->B.chains = ctx->chains.as<uint8_t>();
+  ctx->B.chain_off = ctx->chain_meta.as<uint64_t>();
+  ctx->B.chain_len = ctx->chain_meta.as<uint64_t>() + n_chains;
+  ctx->have_haps = true;
+  ctx->have_plan = false;
+  return SG_OK;
+}
+
+int sg_haplotype_codes(sg_ctx* ctx, uint32_t chain, uint64_t offset, uint64_t n, uint8_t* codes_out) {
+  if (!ctx || (n && !codes_out)) return SG_ERR_INVALID;
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_haplotype_codes: no haplotypes on the device");
+  SG_HIP(hipSetDevice(ctx->device));
+  uint64_t meta[2];
+  // chain_meta = [off_0 .. off_{k-1}, len_0 .. len_{k-1}]; k is recovered from the pointers kept in B
+  const uint64_t k = (uint64_t)(ctx->B.chain_len - ctx->B.chain_off);
+  if (chain >= k) return ctx->fail(SG_ERR_INVALID, "sg_haplotype_codes: chain index out of range");
+  SG_HIP(hipMemcpy(&meta[0], ctx->B.chain_off + chain, 8, hipMemcpyDeviceToHost));
+  SG_HIP(hipMemcpy(&meta[1], ctx->B.chain_len + chain, 8, hipMemcpyDeviceToHost));
+  if (offset + n > meta[1]) return ctx->fail(SG_ERR_INVALID, "sg_haplotype_codes: range past the end of the chain");
+  if (n) SG_HIP(hipMemcpy(codes_out, ctx->B.chains + meta[0] + offset, n, hipMemcpyDeviceToHost));
   return SG_OK;
 }
 

@@ -1,0 +1,162 @@
+// sg_haplotypes.hip -- reference ingest and haplotype assembly on the device.
+//
+// The reference reads one <= 1 Mbp slice per segment through the .fai index, twice per run
+// (lib/fastahack/Fasta.cpp:304-334 via lib/segment/Segment.cpp:137), upper-cases it (Segment.cpp:143),
+// replicates it per haplotype copy and edits the std::strings in place (Segment.cpp:210-447).  Here the
+// FASTA file is streamed to HBM as it is, the contigs are turned into base codes once (newlines
+// dropped by index arithmetic), and a haplotype chain is a list of copies: pieces of the encoded
+// reference or of literal (inserted) bases, followed by single-base patches (SNP / SNV alleles).
+// All of it is HBM-bound byte movement: 1 B read + 1 B written per haplotype base.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "simuscop_amd.h"
+
+namespace sg {
+
+// base codes shared with sg_kernels.hip: A0 C1 T2 G3, 'N' = 4, anything else = 5
+__device__ __forceinline__ uint32_t encode_base(uint32_t b) {
+  if (b >= 'a' && b <= 'z') b -= 32u;  // Segment.cpp:143 (reference slice), :456 (variant alleles)
+  const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
+  return acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : 5u);
+}
+
+// ---- header scan: offsets of '>' / '@' at a line start; ';' comment lines raise flag 1 ----------
+__global__ __launch_bounds__(256) void ref_scan_kernel(const uint8_t* __restrict__ raw, uint64_t n, uint64_t* __restrict__ list,
+                                                       uint32_t cap, uint32_t* __restrict__ count, uint32_t* __restrict__ flags) {
+  for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
+    uint4 w = *(const uint4*)(raw + i);  // the raw buffer is padded to a multiple of 16
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t b = (ws[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+      if (b != '>' && b != '@' && b != ';') continue;
+      const uint64_t p = i + (uint64_t)k;
+      if (p >= n) continue;
+      const bool line_start = p == 0 || raw[p - 1] == '\n';
+      if (!line_start) continue;
+      if (b == ';') { atomicOr(flags, 1u); continue; }
+      const uint32_t slot = atomicAdd(count, 1u);
+      if (slot < cap) list[slot] = p;
+    }
+  }
+}
+
+// ---- contig ingest: raw FASTA lines of fixed width -> base codes ---------------------------------
+struct DevContig {
+  uint64_t raw_off;    // first base in the raw buffer
+  uint64_t code_off;   // first code in the encoded reference
+  uint64_t length;     // bases
+  uint32_t line_bases, line_width;
+  uint64_t first_block;  // exclusive prefix of 16-base blocks over the contigs
+};
+
+// lane = 16 consecutive bases of one contig.  Line structure is verified on the way: a line break
+// byte that is not '\n' / '\r', or a line break byte inside a line, sets flag 2 (the host then falls
+// back to its general parser).
+__global__ __launch_bounds__(256) void ref_ingest_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ codes,
+                                                         const DevContig* __restrict__ contigs, uint32_t n_contigs,
+                                                         uint64_t n_blocks, uint32_t* __restrict__ flags) {
+  for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = n_contigs - 1;  // last contig with first_block <= blk
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (contigs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const DevContig c = contigs[lo];
+    const uint64_t i0 = (blk - c.first_block) * 16;
+    uint64_t line = i0 / c.line_bases;
+    uint32_t r = (uint32_t)(i0 - line * c.line_bases);
+    uint64_t src = c.raw_off + line * c.line_width + r;
+    const uint32_t nl = c.line_width - c.line_bases;
+    uint32_t out[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+    bool bad = false;
+    const uint32_t nb = (uint32_t)(c.length - i0 < 16 ? c.length - i0 : 16);
+    for (uint32_t k = 0; k < nb; k++) {
+      const uint32_t b = raw[src];
+      bad |= (b == '\n') | (b == '\r');
+      out[k >> 2] = (out[k >> 2] & ~(0xFFu << ((k & 3) * 8))) | (encode_base(b) << ((k & 3) * 8));
+      src++;
+      if (++r == c.line_bases) {
+        if (i0 + k + 1 < c.length)  // not after the contig's last base (the file may end without a newline)
+          for (uint32_t t = 0; t < nl; t++) { const uint32_t e = raw[src + t]; bad |= !((e == '\n') | (e == '\r')); }
+        src += nl;
+        r = 0;
+      }
+    }
+    if (bad) atomicOr(flags, 2u);
+    *(uint4*)(codes + c.code_off + i0) = make_uint4(out[0], out[1], out[2], out[3]);  // code_off is 16-aligned
+  }
+}
+
+// ---- haplotype assembly ---------------------------------------------------------------------------
+struct DevPiece { uint64_t dst; uint64_t src; uint32_t len; uint32_t pad; };  // absolute byte offsets
+
+// workgroup per piece (the host splits long pieces): aligned 16-byte stores, unaligned 16-byte loads
+__global__ __launch_bounds__(256) void hap_copy_kernel(uint8_t* __restrict__ chains, const uint8_t* __restrict__ ref_codes,
+                                                       const uint8_t* __restrict__ literals, const DevPiece* __restrict__ pieces,
+                                                       uint64_t n_pieces) {
+  for (uint64_t pi = blockIdx.x; pi < n_pieces; pi += gridDim.x) {
+    const DevPiece p = pieces[pi];
+    const uint8_t* src = ((p.pad & 1u) ? literals : ref_codes) + p.src;
+    uint8_t* dst = chains + p.dst;
+    const uint64_t d0 = p.dst, d1 = p.dst + p.len;
+    const uint64_t a0 = (d0 + 15) & ~(uint64_t)15, a1 = d1 & ~(uint64_t)15;  // aligned interior [a0, a1)
+    if (a0 >= a1) {
+      for (uint32_t i = threadIdx.x; i < p.len; i += blockDim.x) dst[i] = src[i];
+      continue;
+    }
+    const uint32_t head = (uint32_t)(a0 - d0), tail = (uint32_t)(d1 - a1);
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < tail) dst[p.len - tail + threadIdx.x] = src[p.len - tail + threadIdx.x];
+    const uint64_t nblk = (a1 - a0) / 16;
+    for (uint64_t b = threadIdx.x; b < nblk; b += blockDim.x) {
+      uint4 w;
+      __builtin_memcpy(&w, src + head + b * 16, 16);
+      *(uint4*)(dst + head + b * 16) = w;
+    }
+  }
+}
+
+struct DevPatch { uint64_t dst; uint32_t base; uint32_t pad; };
+__global__ __launch_bounds__(256) void hap_patch_kernel(uint8_t* __restrict__ chains, const DevPatch* __restrict__ patches, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    chains[patches[i].dst] = (uint8_t)encode_base(patches[i].base);
+}
+
+__global__ __launch_bounds__(256) void encode_bytes_kernel(uint8_t* __restrict__ buf, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    buf[i] = (uint8_t)encode_base(buf[i]);
+}
+
+// ---- launchers -------------------------------------------------------------------------------------
+static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t max_blocks) {
+  uint64_t g = (items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (uint32_t)(g > max_blocks ? max_blocks : g);
+}
+void launch_ref_scan(const uint8_t* raw, uint64_t n, uint64_t* list, uint32_t cap, uint32_t* count, uint32_t* flags, hipStream_t s) {
+  hipLaunchKernelGGL(ref_scan_kernel, dim3(grid_for((n + 15) / 16, 256, 256 * 32)), dim3(256), 0, s, raw, n, list, cap, count, flags);
+}
+void launch_ref_ingest(const uint8_t* raw, uint8_t* codes, const void* contigs, uint32_t n_contigs, uint64_t n_blocks,
+                       uint32_t* flags, hipStream_t s) {
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(ref_ingest_kernel, dim3(grid_for(n_blocks, 256, 256 * 64)), dim3(256), 0, s, raw, codes,
+                     (const DevContig*)contigs, n_contigs, n_blocks, flags);
+}
+void launch_hap_copy(uint8_t* chains, const uint8_t* ref_codes, const uint8_t* literals, const void* pieces, uint64_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(hap_copy_kernel, dim3(grid_for(n, 1, 256 * 64)), dim3(256), 0, s, chains, ref_codes, literals,
+                     (const DevPiece*)pieces, n);
+}
+void launch_hap_patch(uint8_t* chains, const void* patches, uint64_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(hap_patch_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, chains, (const DevPatch*)patches, n);
+}
+void launch_encode_bytes(uint8_t* buf, uint64_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(encode_bytes_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, buf, n);
+}
+
+}  // namespace sg
