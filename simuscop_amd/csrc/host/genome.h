@@ -82,6 +82,7 @@ struct Genome {
   // lists instead of strings
   bool device_haps = false;
   ::sg_ctx* engine = nullptr;
+  double t_reference = 0;  // seconds spent in Fasta::open / open_on_device
 
   explicit Genome(Config& c) : cfg(c) {}
 

@@ -401,11 +401,14 @@ struct Driver {
     cfg.load(config_path);
     seed = opt.has_seed ? opt.seed : (uint64_t)cfg.num["seed"];
     const int device = opt.device >= 0 ? opt.device : (int)cfg.num["device"];
+    auto t1 = Clock::now();
     if (sg_create(&eng.ctx, device, seed) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(nullptr));
     sg_set_profiling(eng.ctx, 1);
+    st.t_engine = since(t1);
     genome.device_haps = !opt.host_haplotypes;
     genome.engine = eng.ctx;
     genome.load_data();
+    st.t_reference = genome.t_reference;
     const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
     if (opt.write_files) mkdir(out_dir.c_str(), 0755);  // src/simuReads.cpp:56-60
     (void)out_dir;

@@ -39,6 +39,8 @@ typedef struct simu_stats {
   float kernel_ms[8];      // summed per kernel (SG_K_*)
   uint64_t queued_items;   // items the fast emit kernel left to the generic item code (sg_emit_info)
   uint64_t requeued_batches;  // batches emitted again because that queue overflowed
+  double t_engine;         // part of t_load: sg_create (HIP context, stream)
+  double t_reference;      // part of t_load: reference FASTA to its resident form (host strings or device codes)
 } simu_stats;
 
 // Returns 0 on success.  On failure returns the exit code the reference would use and writes the

@@ -2,6 +2,7 @@
 // abundance matrix.  Formats and error texts follow the reference
 // (lib/genome/Genome.cpp:41-339, lib/snp/snp.cpp:12-35,147-203).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -163,8 +164,10 @@ void Genome::load_abundance() {
 void Genome::load_data() {
   load_variations();
   load_snps();
+  const auto t0 = std::chrono::steady_clock::now();
   if (device_haps) fa.open_on_device(cfg.str["ref"], engine, (int)std::max<long long>(1, cfg.num["threads"]));
   else fa.open(cfg.str["ref"]);
+  t_reference = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   chromosomes = fa.names;
   load_targets();
   divide_targets();
