@@ -81,7 +81,7 @@ class SimuStats(C.Structure):
                 ("t_plan", C.c_double), ("t_sample", C.c_double), ("t_fetch", C.c_double),
                 ("t_write", C.c_double), ("t_total", C.c_double), ("kernel_ms", C.c_float * 8),
                 ("queued_items", C.c_uint64), ("requeued_batches", C.c_uint64), ("t_engine", C.c_double),
-                ("t_reference", C.c_double)]
+                ("t_reference", C.c_double), ("t_hap_device", C.c_double), ("t_plan_api", C.c_double)]
 
 
 _engine = None

@@ -91,6 +91,8 @@ struct Driver {
     const std::string key = popu + "\t" + chr;
     if (resident == key) return;
     ChromPlan& plan = genome.plans[popu][chr];
+    auto t_up = Clock::now();
+    struct Acc { double& d; Clock::time_point t; ~Acc() { d += since(t); } } acc{st.t_hap_device, t_up};
     if (genome.device_haps) {
       eng.check(sg_build_haplotypes(eng.ctx, (int32_t)plan.chain_len.size(), plan.chain_len.data(), plan.pieces.data(),
                                     plan.pieces.size(), plan.literals.data(), plan.literals.size(), plan.patches.data(),
@@ -128,10 +130,17 @@ struct Driver {
     eng.check(sg_gc_percent(eng.ctx, gcw.data(), gcw.size(), gcv.data()), "sg_gc_percent");
     const uint32_t ctx24 = genome.host_ctx(popu, chr);
     const unsigned frag = Genome::kFragSize;
-    size_t q = 0;
+    // GC factor per window: an addressed draw (segment, window), so segments are independent work
+    std::vector<size_t> q0(plan.segs.size() + 1, 0);
     for (size_t k = 0; k < plan.segs.size(); k++) {
       const Segment& g = plan.segs[k];
-      if (!g.has_seq || (!genome.targets.empty() && g.targets.empty())) continue;
+      const bool live = g.has_seq && !(!genome.targets.empty() && g.targets.empty());
+      q0[k + 1] = q0[k] + (live ? g.w1 - g.w0 : 0);
+    }
+    auto weigh_segment = [&](size_t k) {
+      const Segment& g = plan.segs[k];
+      if (q0[k + 1] == q0[k]) return;
+      size_t q = q0[k];
       for (uint32_t w = g.w0; w < g.w1; w++, q++) {
         const double f = prof.gc_factor(gcv[q], seed, ctx24, (uint32_t)k, w - g.w0);
         // full 1 kbp tiles: factor/fragSize; tails and targets: factor*len/(fragSize*fragSize)
@@ -139,6 +148,18 @@ struct Driver {
         if (genome.targets.empty() && plan.w_len[w] == frag) plan.w_weight[w] = f / frag;
         else plan.w_weight[w] = f * (unsigned long)plan.w_len[w] / (frag * frag);
       }
+    };
+    const size_t nthreads = std::min<size_t>((size_t)std::max<long long>(1, cfg.num["threads"]), plan.segs.size() / 4 + 1);
+    if (nthreads <= 1) {
+      for (size_t k = 0; k < plan.segs.size(); k++) weigh_segment(k);
+    } else {
+      std::atomic<size_t> next(0);
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < nthreads; t++)
+        pool.emplace_back([&]() {
+          for (size_t k; (k = next.fetch_add(1)) < plan.segs.size();) weigh_segment(k);
+        });
+      for (std::thread& th : pool) th.join();
     }
     plan.weighed = true;
     st.t_plan += since(t0);
@@ -304,7 +325,9 @@ struct Driver {
     b.n_segs = (uint32_t)sh_size.size();
     b.first_window = w_lo;
     b.first_slot = slot_lo;
+    auto t_pl = Clock::now();
     eng.check(sg_plan(eng.ctx, &b), "sg_plan");
+    st.t_plan_api += since(t_pl);
     st.t_sample += since(t0);
     return true;
   }

@@ -41,6 +41,8 @@ typedef struct simu_stats {
   uint64_t requeued_batches;  // batches emitted again because that queue overflowed
   double t_engine;         // part of t_load: sg_create (HIP context, stream)
   double t_reference;      // part of t_load: reference FASTA to its resident form (host strings or device codes)
+  double t_hap_device;     // part of t_plan/t_sample: sg_build_haplotypes / sg_upload_haplotypes calls
+  double t_plan_api;       // part of t_sample: sg_plan calls (window upload, work buffers)
 } simu_stats;
 
 // Returns 0 on success.  On failure returns the exit code the reference would use and writes the
