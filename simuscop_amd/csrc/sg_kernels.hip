@@ -924,6 +924,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
   uint4* tail_all = (uint4*)(slow_all + EMIT_WAVES * SLOW_CAP);
+  uint8_t* perm_all = (uint8_t*)(tail_all + EMIT_WAVES * 64);
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   // staging with the fast kernel's digit / base-order permutations
   for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
@@ -949,6 +950,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
   uint4* tail_rows = tail_all + wv * 64;
+  uint8_t* perm = perm_all + wv * 64;
 
   const uint32_t G = RPI * (64u / RPI);
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
@@ -975,9 +977,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
     wave_lds_sync();
-    const uint32_t nmain = (G + RPI - 1u) / RPI;
-    unsigned long long more = __ballot(items > TI);
-    uint32_t cb = TI;
     uint32_t nslow = 0;  // wave-uniform
     // Items the straight-line code cannot do (non-ACGT window, >= 2 indels) go to the batch's global
     // queue: one atomic per flush reserves the range; emit_slow_kernel runs the generic code on them
@@ -998,6 +997,39 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       nslow = 0;
       wave_lds_sync();
     };
+    // Order of the group's reads through the step loop: reads without a sequencing indel first, then
+    // the reads with one (so that the two-window code runs in ~4 of 21 steps instead of whenever one
+    // of a step's reads has an event, 42 % of the steps at XTen rates).  Reads with >= 2 events never
+    // enter the loop: all their items are queued here.
+    const uint32_t nev_l = (my1.y >> 16) & 0xFu;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long in_group = G >= 64u ? ~0ull : ((1ull << G) - 1ull);
+    const unsigned long long m_multi = __ballot(items > 0u && nev_l >= 2u);
+    const unsigned long long m_one = __ballot(items > 0u && nev_l == 1u);
+    const unsigned long long m_rest = in_group & ~(m_multi | m_one);
+    const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_fast = n_rest + (uint32_t)__popcll(m_one);
+    if (lane < G) {
+      uint32_t pos;
+      if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
+      else if ((m_one >> lane) & 1ull) pos = n_rest + (uint32_t)__popcll(m_one & lt);
+      else pos = n_fast + (uint32_t)__popcll(m_multi & lt);
+      perm[pos] = (uint8_t)lane;
+    }
+    for (unsigned long long mm = m_multi; mm; mm &= mm - 1ull) {
+      const uint32_t rr = (uint32_t)__builtin_ctzll(mm);
+      const uint32_t nit = ((meta_rows[rr * 2 + 1].y & 0xFFFFu) + 7u) / 8u;
+      for (uint32_t c0 = 0; c0 < nit; c0 += 64u) {
+        const uint32_t cnt = min(64u, nit - c0);
+        if (nslow + cnt > SLOW_CAP) flush_slow();
+        if (lane < cnt) slow_list[nslow + lane] = rr | ((c0 + lane) << 8);
+        nslow += cnt;
+      }
+      if (lane == 0u) tail_rows[rr].x = 0xFFFFFFFFu;  // its last item is not in a tail row
+    }
+    wave_lds_sync();
+    const uint32_t nmain = (n_fast + RPI - 1u) / RPI;
+    unsigned long long more = __ballot(items > TI && nev_l < 2u);
+    uint32_t cb = TI;
     for (uint32_t step = 0;; step++) {
       const bool done = step >= nmain && !more;
       if (done || nslow > SLOW_CAP - 64u) {
@@ -1008,10 +1040,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       bool ok;
       uint32_t o0 = hoff0, a0 = hw0, k0_ = hk0, o1 = hoff1, a1 = hw1, k1_ = hk1;
       if (step < nmain) {
-        r = step * RPI + sub;
+        const uint32_t ri = step * RPI + sub;
         c = c_lane;
-        ok = lane_ok && r < G;
-        if (!ok) r = step * RPI;
+        ok = lane_ok && ri < n_fast;
+        r = perm[ok ? ri : step * RPI];
       } else {
         r = (uint32_t)__builtin_ctzll(more);
         c = cb + lane;   // items past the fixed map are never the first item of a read
@@ -1206,7 +1238,8 @@ static EmitLds emit_lds(const DevProfile& P) {
   e.sub_rows = kmer_count * (uint32_t)P.bins;
   e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
   e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 * 16;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 * 16 +
+                       (size_t)EMIT_WAVES * 64;
   const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
   const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
   e.sub_lds = fixed + sub_b <= kLdsBytes;
