@@ -1103,15 +1103,26 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   }
 }
 
-// The queued items of emit_fast_kernel, one lane each, through the generic item code (tables via L2).
-__global__ __launch_bounds__(256) void emit_slow_kernel(DevProfile P, DevBatch B) {
-  const uint32_t m = blockIdx.y, lane = threadIdx.x & 63u;
+// The queued items of emit_fast_kernel, one lane each, through the generic item code; the tables are
+// staged in LDS like in emit_kernel when they fit (persistent workgroup per CU, grid-stride over the queue).
+template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words) {
+  extern __shared__ uint4 smem[];
+  const uint32_t m = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
   const uint32_t tm = B.paired ? m : 0u;
-  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   uint32_t n = B.slowq_count[m];
   if (n > B.slowq_cap) n = B.slowq_cap;  // overflow: the host reruns the batch through emit_kernel
+  if ((blockIdx.x * EMIT_THREADS) >= n) return;  // nothing for this workgroup: skip the staging too
+  uint4* lds_sub = smem;
+  uint32_t* lds_qual = (uint32_t*)(smem + (SUB_LDS ? sub_rows : 0u));
+  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
+  if (SUB_LDS)
+    for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) lds_sub[i] = gsub[i];
+  if (QUAL_LDS)
+    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) lds_qual[i] = P.qual[i];
+  __syncthreads();
   const uint2* q = B.slowq + (size_t)m * B.slowq_cap;
-  for (uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) & ~63u; b0 < n; b0 += gridDim.x * 256u) {
+  for (uint32_t b0 = (blockIdx.x * EMIT_THREADS + tid) & ~63u; b0 < n; b0 += gridDim.x * EMIT_THREADS) {
     const uint32_t i = b0 + lane;
     const bool act = i < n;
     const uint2 e = q[act ? i : b0];
@@ -1121,7 +1132,7 @@ __global__ __launch_bounds__(256) void emit_slow_kernel(DevProfile P, DevBatch B
     const uint64_t ooff = B.recoff[idx];
     m0.z = (uint32_t)ooff;
     m0.w = (uint32_t)(ooff >> 32);
-    emit_item<0, 0, false, false>(P, B, nullptr, nullptr, gsub, m, m0, m1, e.x, e.y, act);
+    emit_item<KT, QLG, SUB_LDS, QUAL_LDS>(P, B, lds_sub, lds_qual, gsub, m, m0, m1, e.x, e.y, act);
   }
 }
 
@@ -1296,7 +1307,18 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     else launch_fast(emit_fast_kernel<false, true>, e.lds_diag, e.diag_words);
   }
   if (mode != 0) {
-    hipLaunchKernelGGL(emit_slow_kernel, dim3((uint32_t)cus * 4u, nm), dim3(256), 0, s, P, B);
+    // generic-code layout of the tables (no permutation): sub rows + the whole quality table when they fit
+    const size_t slow_sub = sub_lds ? (size_t)sub_rows * 16 : 0;
+    const size_t slow_qual = (sub_lds && slow_sub + (((size_t)qual_words * 4 + 15) & ~(size_t)15) <= kLdsBytes) ? (((size_t)qual_words * 4 + 15) & ~(size_t)15) : 0;
+    const dim3 sgrid(gx, nm);
+    auto launch_slow = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slow_sub + slow_qual));
+      hipLaunchKernelGGL(kern, sgrid, dim3(EMIT_THREADS), slow_sub + slow_qual, s, P, B, sub_rows, qual_words);
+    };
+    if (slow_sub && slow_qual && P.qual_w == 8) launch_slow(emit_slow_kernel<3, 3, true, true>);
+    else if (slow_sub && slow_qual) launch_slow(emit_slow_kernel<0, 0, true, true>);
+    else if (slow_sub) launch_slow(emit_slow_kernel<0, 0, true, false>);
+    else launch_slow(emit_slow_kernel<0, 0, false, false>);
   } else if (P.kmer == 3 && P.qual_w == 8 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
