@@ -495,7 +495,13 @@ struct ReadCtx {
   uint32_t ctx24() const { return ((uint32_t)mate << 23) | (batch & 0xFFFFu); }
   uint32_t indel(int j, int which) {  // which: 0 insert test, 1 deletion test  (real stream)
     if (!rng->philox) return rng->realGen();
-    return rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 1), 0, (j & 1) * 2 + which);
+    // One 32-bit uniform = two independent 16-bit halves: the high halves of four template positions
+    // share the words of call (j/4, c2 = 0), the low halves those of call (j/4, c2 = 1) -- so that a
+    // consumer can decide `x <= T` from the first call alone unless its high half equals T's.
+    const uint32_t hw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 2), 0, j & 3);
+    const uint32_t lw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 2), 1, j & 3);
+    const uint32_t hi = which == 0 ? hw >> 16 : hw & 0xFFFFu, lo = which == 0 ? lw >> 16 : lw & 0xFFFFu;
+    return (hi << 16) | lo;
   }
   uint32_t aux(int j, int f, bool intStream) {  // f=0 indel length (real), f>=1 inserted base f-1 (int)
     if (!rng->philox) return intStream ? rng->intGen() : rng->realGen();

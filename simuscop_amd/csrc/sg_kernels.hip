@@ -193,16 +193,31 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   uint32_t nev = 0, first_ev = 0;
   uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
   const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
-  for (int c = 0; 2 * c < L; c++) {
+  // Insert / deletion tests of four template positions per Philox call: word k of call (c, 0) holds the
+  // HIGH 16 bits of ins(4c+k) and del(4c+k), word k of call (c, 1) the low 16 bits.  `x <= T` is decided
+  // by the high half unless it equals T's (2 in 65536), so the second call is rare.
+  const uint32_t ThiI = P.Tins >> 16, TloI = P.Tins & 0xFFFFu, ChiD = P.Cdel >> 16, CloD = P.Cdel & 0xFFFFu;
+  for (int c = 0; 4 * c < L; c++) {
+    if (4 * c + 3 < j) continue;  // all four positions were consumed by a deletion
     uint32_t x[4];
     philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
+    // 99.5 % of the calls end here: no position whose high half reaches a threshold's high half
+    bool cand = false;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int jj = 2 * c + h;
-      if (jj >= L || jj < j) continue;
-      const uint32_t xi = x[2 * h], xd = x[2 * h + 1];
-      j = jj + 1;
-      if (xi <= P.Tins) {
+    for (int h = 0; h < 4; h++) cand |= (x[h] >> 16) <= ThiI || (x[h] & 0xFFFFu) <= ChiD;
+    if (!cand) continue;
+    uint32_t y[4];
+    philox4x32_10(t + B.slot_offset, (uint32_t)c, 1, c3, B.k0, B.k1, y);
+#pragma unroll 1
+    for (int h = 0; h < 4; h++) {
+      const int jj = 4 * c + h;
+      if (jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
+      const uint32_t xw = h == 0 ? x[0] : h == 1 ? x[1] : h == 2 ? x[2] : x[3];
+      const uint32_t yw = h == 0 ? y[0] : h == 1 ? y[1] : h == 2 ? y[2] : y[3];
+      const uint32_t hi_i = xw >> 16, hi_d = xw & 0xFFFFu;
+      const bool is_ins = hi_i < ThiI || (hi_i == ThiI && (yw >> 16) <= TloI);
+      const bool is_del = hi_d < ChiD || (hi_d == ChiD && (yw & 0xFFFFu) < CloD);
+      if (is_ins) {
         uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
           if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, len, 0);
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
           nev++;
           dl += (int)len;
         }
-      } else if (xd < P.Cdel) {
+      } else if (is_del) {
         uint32_t len = row_search(P.del_row, P.del_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
           uint32_t k = min((uint32_t)(L - jj), len);
