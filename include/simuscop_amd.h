@@ -33,7 +33,7 @@ extern "C" {
 #define SG_ERR_OVERFLOW 4    /* more than SG_MAX_EVENTS sequencing indels in one read             */
 #define SG_ERR_FORMAT 5      /* FASTA without fixed-width lines (sg_reference_commit): use the host parser */
 
-#define SG_MAX_EVENTS 8
+#define SG_MAX_EVENTS 32
 
 typedef struct sg_ctx sg_ctx;
 

@@ -556,7 +556,7 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
   if (b->n_segs && (b->seg_first_window[0] != 0 || b->seg_first_window[b->n_segs] != nw))
     return ctx->fail(SG_ERR_INVALID, "sg_plan: seg_first_window must cover all windows");
   const size_t plen = b->name_prefix ? strlen(b->name_prefix) : 0;
-  if (plen == 0 || plen > 4096) return ctx->fail(SG_ERR_INVALID, "sg_plan: bad name_prefix");
+  if (plen == 0 || plen > 990) return ctx->fail(SG_ERR_INVALID, "sg_plan: bad name_prefix (1..990 bytes)");  // header length is a 10-bit field
   // chain bounds need the chain lengths: read them back once (tiny)
   {
     const size_t nch = (size_t)(ctx->B.chain_len - ctx->B.chain_off);

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
   // (sg_load_profile rejects profiles that could violate the bound)
   // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
-  B.meta[idx * 4 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 20), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
+  B.meta[idx * 4 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
   if (hdr <= 32u) {
     uint32_t* hp = (uint32_t*)(B.meta + idx * 4 + 2);
     uint32_t w = 0, nb = 0;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void header_kernel(DevBatch B, uint32_t only_l
   const size_t idx = (size_t)m * B.n_slots + t;
   const uint4 m1 = B.meta[idx * 4 + 1];
   if (!(m1.x & 0x7FFFFFFFu)) return;
-  if (only_long && (m1.y >> 20) <= 32u) return;  // written by the emit kernel from the row
+  if (only_long && (m1.y >> 22) <= 32u) return;  // written by the emit kernel from the row
   const uint4 m0 = B.meta[idx * 4];
   const uint64_t ooff = B.recoff[idx];
   if (ooff + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
@@ -511,7 +511,7 @@ __device__ __noinline__ uint64_t slow_codes(const uint8_t* frag, uint32_t flen, 
 }
 
 // One item = output positions [8c, 8c+8) of one read: sample and store bases + qualities.
-//   m0 = {frag_lo, frag_hi, out_lo, out_hi}   m1 = {flen | rev<<31, np | nev<<16 | hdr<<20, inv, -}
+//   m0 = {frag_lo, frag_hi, out_lo, out_hi}   m1 = {flen | rev<<31, np | nev<<16 (6 bits) | hdr<<22, inv, -}
 template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
 __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
                                           const uint32_t* lds_qual, const uint4* gsub, uint32_t m, const uint4 m0,
@@ -521,7 +521,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   const uint32_t ctxmask = (1u << (2 * K)) - 1u;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = (m1.x >> 31) != 0;
-  const uint32_t np = m1.y & 0xFFFFu, nev = (B.diag & 32u) ? 0u : ((m1.y >> 16) & 0xFu), hdr = m1.y >> 20;
+  const uint32_t np = m1.y & 0xFFFFu, nev = (B.diag & 32u) ? 0u : ((m1.y >> 16) & 0x3Fu), hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
   const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
@@ -778,7 +778,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
-  const uint32_t np = m1.y & 0xFFFFu, nev = (m1.y >> 16) & 0xFu, hdr = m1.y >> 20;
+  const uint32_t np = m1.y & 0xFFFFu, nev = (m1.y >> 16) & 0x3Fu, hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
   const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // the reads with one (so that the two-window code runs in ~4 of 21 steps instead of whenever one
     // of a step's reads has an event, 42 % of the steps at XTen rates).  Reads with >= 2 events never
     // enter the loop: all their items are queued here.
-    const uint32_t nev_l = (my1.y >> 16) & 0xFu;
+    const uint32_t nev_l = (my1.y >> 16) & 0x3Fu;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long in_group = G >= 64u ? ~0ull : ((1ull << G) - 1ull);
     const unsigned long long m_multi = __ballot(items > 0u && nev_l >= 2u);
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     if (lane < G && t < B.n_slots) {
       const uint4 r0 = meta_rows[lane * 2], r1 = meta_rows[lane * 2 + 1];
       if (r1.x & 0x7FFFFFFFu) {
-        const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 20;
+        const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
         uint8_t* rec = B.out[m] + (((uint64_t)r0.w << 32) | r0.z);
         if (hl <= 32u) {
           const uint4* hrow = B.meta + ((size_t)m * B.n_slots + t) * 4 + 2;
