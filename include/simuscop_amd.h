@@ -194,8 +194,9 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
 #define SG_K_NAMEBASE 1
 #define SG_K_INDEL 2
 #define SG_K_SCAN 3
-#define SG_K_EMIT 4
-#define SG_K_COUNT 5
+#define SG_K_EMIT 4       /* header + main emit kernel                                   */
+#define SG_K_EMIT_SLOW 5  /* emit_slow_kernel: the items queued for the generic item code */
+#define SG_K_COUNT 6
 /* When enabled, HIP events bracket every kernel of sg_sample on the ctx's stream;
  * sg_kernel_times() then returns the last pass's per-kernel milliseconds (after sg_result).     */
 int sg_set_profiling(sg_ctx* ctx, int enable);

@@ -16,7 +16,7 @@ ENGINE_SO = os.path.join(LIB_DIR, "libsimuscop_amd.so")
 HOST_SO = os.path.join(LIB_DIR, "libsimuscop_host.so")
 SIMUREADS = os.path.join(LIB_DIR, "simuReads")
 
-SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit"]
+SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit", "emit_slow"]
 
 # every symbol include/simuscop_amd.h declares
 ENGINE_SYMBOLS = [

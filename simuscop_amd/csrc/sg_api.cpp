@@ -22,7 +22,7 @@ void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
-void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic);
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main);
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
@@ -81,9 +81,9 @@ struct sg_ctx {
   bool results_valid = false;
 
   bool profiling = false;
-  hipEvent_t evs[SG_K_COUNT + 2] = {};  // starts of plan..scan, end of scan, start/end of emit
+  hipEvent_t evs[8] = {};  // 0-3 starts of plan..scan, 4 end of scan, 5 start of emit, 6 end of emit, 7 between the two emit kernels
   bool evs_created = false;
-  float last_ms[SG_K_COUNT] = {0, 0, 0, 0, 0};
+  float last_ms[SG_K_COUNT] = {0, 0, 0, 0, 0, 0};
 
   int fail(int code, const std::string& m) { err = m; return code; }
   int hipfail(hipError_t e, const char* what) {
@@ -671,7 +671,7 @@ static int run_pass(sg_ctx* ctx) {
   }
   if (prof) SG_HIP(hipEventRecord(ctx->evs[5], s));  // after the (first-pass) output allocation
   sg::launch_header(ctx->P, B, s);
-  sg::launch_emit(ctx->P, B, s, false);
+  sg::launch_emit(ctx->P, B, s, false, prof ? ctx->evs[7] : nullptr);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[6], s));
   SG_HIP(hipMemcpyAsync(ctx->host_flags, B.totals + 3, 2 * 8, hipMemcpyDeviceToHost, s));
   SG_HIP(hipGetLastError());
@@ -704,14 +704,15 @@ int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_f
     ctx->slow_items = (ctx->host_flags[1] & 0xFFFFFFFFu) + (ctx->host_flags[1] >> 32);
     ctx->slow_overflow = (ctx->host_flags[0] & 2) != 0;
     if (ctx->slow_overflow) {  // headers are in place; every item again through the generic kernel
-      sg::launch_emit(ctx->P, ctx->B, ctx->stream, true);
+      sg::launch_emit(ctx->P, ctx->B, ctx->stream, true, nullptr);
       SG_HIP(hipGetLastError());
       SG_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
   if (ctx->profiling) {
-    for (int i = 0; i < SG_K_COUNT - 1; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
-    SG_HIP(hipEventElapsedTime(&ctx->last_ms[SG_K_EMIT], ctx->evs[5], ctx->evs[6]));
+    for (int i = 0; i < 4; i++) SG_HIP(hipEventElapsedTime(&ctx->last_ms[i], ctx->evs[i], ctx->evs[i + 1]));
+    SG_HIP(hipEventElapsedTime(&ctx->last_ms[SG_K_EMIT], ctx->evs[5], ctx->evs[7]));
+    SG_HIP(hipEventElapsedTime(&ctx->last_ms[SG_K_EMIT_SLOW], ctx->evs[7], ctx->evs[6]));
   }
   ctx->results_valid = true;
   if (bytes_r1) *bytes_r1 = ctx->host_totals[0];

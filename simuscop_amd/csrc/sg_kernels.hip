@@ -1288,8 +1288,11 @@ bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
   (void)B;
   return emit_fast_mode(P) != 0;
 }
-void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic) {
-  if (!B.n_slots) return;
+void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main) {
+  if (!B.n_slots) {
+    if (after_main) (void)hipEventRecord(after_main, s);
+    return;
+  }
   const EmitLds e = emit_lds(P);
   const uint32_t sub_rows = e.sub_rows, qual_words = e.qual_words;
   const size_t lds = e.lds;
@@ -1322,6 +1325,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     else launch_fast(emit_fast_kernel<false, true>, e.lds_diag, e.diag_words);
   }
   if (mode != 0) {
+    if (after_main) (void)hipEventRecord(after_main, s);
     // generic-code layout of the tables (no permutation): sub rows + the whole quality table when they fit
     const size_t slow_sub = sub_lds ? (size_t)sub_rows * 16 : 0;
     const size_t slow_qual = (sub_lds && slow_sub + (((size_t)qual_words * 4 + 15) & ~(size_t)15) <= kLdsBytes) ? (((size_t)qual_words * 4 + 15) & ~(size_t)15) : 0;
@@ -1338,6 +1342,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
   else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
   else launch_emit_variant<0, 0, false, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
+  if (mode == 0 && after_main) (void)hipEventRecord(after_main, s);
 }
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s) {  // bytes is a multiple of 16
   if (!bytes) return;
