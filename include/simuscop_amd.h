@@ -197,6 +197,21 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
 #define SG_K_EMIT 4       /* header + main emit kernel                                   */
 #define SG_K_EMIT_SLOW 5  /* emit_slow_kernel: the items queued for the generic item code */
 #define SG_K_COUNT 6
+/* ---- block-gzip sink ------------------------------------------------------------ */
+/* After sg_result: compress the FASTQ text of the pass on the device into BGZF blocks -- independent
+ * gzip members of 32 KB of text each (RFC 1952 with the 'BC' extra field), literal-only dynamic-Huffman
+ * DEFLATE, one code per mate and pass.  Concatenated in order (and closed with sg_bgzf_eof) they form
+ * a .fq.gz file that `zcat` turns back into exactly the text sg_fetch returns.  SeqWriter::write
+ * (lib/seqwriter/SeqWriter.cpp:41-54) has no such mode: additive.                                   */
+int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2);
+int sg_fetch_compressed(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, void* host_dst);
+/* the 28-byte empty BGZF block that ends a file */
+int sg_bgzf_eof(uint8_t out[28]);
+/* Host-only view of the code construction, for tests: from a byte histogram, the literal / end-of-block
+ * code lengths and (bit-reversed) codes and the member prefix (gzip header with BSIZE = 0 + dynamic
+ * block header) as LSB-first 32-bit words.  Returns the number of prefix bits, 0 if `cap` is too small. */
+uint32_t sg_deflate_plan(const uint64_t counts[256], uint8_t lens[257], uint32_t codes[257], uint32_t* prefix_words, uint32_t cap);
+
 /* When enabled, HIP events bracket every kernel of sg_sample on the ctx's stream;
  * sg_kernel_times() then returns the last pass's per-kernel milliseconds (after sg_result).     */
 int sg_set_profiling(sg_ctx* ctx, int enable);

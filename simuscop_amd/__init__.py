@@ -22,7 +22,8 @@ SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit", "emit_slow"]
 ENGINE_SYMBOLS = [
     "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
     "sg_upload_haplotypes", "sg_reference_begin", "sg_reference_chunk", "sg_sync", "sg_reference_scan",
-    "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
+    "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_compress", "sg_fetch_compressed",
+    "sg_bgzf_eof", "sg_deflate_plan", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_host_free",
 ]
@@ -71,7 +72,7 @@ class SgHapPatch(C.Structure):
 class SimuOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("has_seed", C.c_int32), ("seed", C.c_uint64), ("write_files", C.c_int32),
                 ("fetch", C.c_int32), ("quiet", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32)]
+                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32), ("gzip", C.c_int32)]
 
 
 class SimuStats(C.Structure):
@@ -81,7 +82,7 @@ class SimuStats(C.Structure):
                 ("t_plan", C.c_double), ("t_sample", C.c_double), ("t_fetch", C.c_double),
                 ("t_write", C.c_double), ("t_total", C.c_double), ("kernel_ms", C.c_float * 8),
                 ("queued_items", C.c_uint64), ("requeued_batches", C.c_uint64), ("t_engine", C.c_double),
-                ("t_reference", C.c_double), ("t_hap_device", C.c_double), ("t_plan_api", C.c_double)]
+                ("t_reference", C.c_double), ("t_hap_device", C.c_double), ("t_plan_api", C.c_double), ("t_compress", C.c_double), ("gz_bytes", C.c_uint64)]
 
 
 _engine = None
@@ -115,6 +116,11 @@ def load_engine():
     lib.sg_build_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(SgHapPiece), C.c_uint64,
                                         C.c_char_p, C.c_uint64, C.POINTER(SgHapPatch), C.c_uint64]
     lib.sg_haplotype_codes.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p]
+    lib.sg_compress.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.sg_fetch_compressed.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p]
+    lib.sg_bgzf_eof.argtypes = [C.c_char_p]
+    lib.sg_deflate_plan.argtypes = [C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
+    lib.sg_deflate_plan.restype = C.c_uint32
     lib.sg_plan.argtypes = [vp, C.POINTER(SgBatch)]
     lib.sg_sample.argtypes = [vp]
     lib.sg_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -253,6 +259,17 @@ class Session:
         ms = (C.c_float * 8)()
         self._sg(self.eng.sg_kernel_times(self.ctx, ms), "sg_kernel_times")
         return {n: float(ms[i]) for i, n in enumerate(SG_K_NAMES)}
+
+    def compress(self):
+        """BGZF-compress the FASTQ text of the last pass on the device; returns the compressed sizes."""
+        g1, g2 = C.c_uint64(), C.c_uint64()
+        self._sg(self.eng.sg_compress(self.ctx, C.byref(g1), C.byref(g2)), "sg_compress")
+        return g1.value, g2.value
+
+    def fetch_compressed(self, mate: int, nbytes: int, offset: int = 0) -> bytes:
+        buf = C.create_string_buffer(max(nbytes, 1))
+        self._sg(self.eng.sg_fetch_compressed(self.ctx, mate, offset, nbytes, buf), "sg_fetch_compressed")
+        return buf.raw[:nbytes]
 
     def emit_info(self):
         """(items handed to the generic item code, whether the batch was re-emitted) of the last pass."""

@@ -1,6 +1,6 @@
 // host/main.cpp -- `simuReads <configuration file>` (src/simuReads.cpp:24-97), GPU-backed.
 // Same positional argument, usage text and exit codes; optional flags are additive:
-//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes
+//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes  --gzip
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +42,7 @@ int main(int argc, char* argv[]) {
     else if (a == "--world") opt.shard_world = atoi(val());
     else if (a == "--stats") stats = true;
     else if (a == "--host-haplotypes") opt.host_haplotypes = 1;
+    else if (a == "--gzip") opt.gzip = 1;
     else if (config.empty()) config = a;
     else {
       std::cerr << "Error: too many input arguments!" << std::endl;
@@ -63,12 +64,12 @@ int main(int argc, char* argv[]) {
   if (stats)
     fprintf(stderr,
             "stats: reads=%llu fragments=%llu bytes=%llu windows=%llu segments=%llu batches=%llu | load %.3fs (engine %.3fs reference %.3fs) haplotypes %.3fs "
-            "plan %.3fs sample %.3fs (haplotype calls %.3fs sg_plan %.3fs) fetch %.3fs write %.3fs total %.3fs | kernels ms: plan %.3f namebase %.3f indel %.3f scan %.3f emit %.3f emit_slow %.3f | queued_items=%llu requeued_batches=%llu\n",
+            "plan %.3fs sample %.3fs (haplotype calls %.3fs sg_plan %.3fs) fetch %.3fs write %.3fs total %.3fs | kernels ms: plan %.3f namebase %.3f indel %.3f scan %.3f emit %.3f emit_slow %.3f | queued_items=%llu requeued_batches=%llu | compress %.3fs gz_bytes=%llu\n",
             (unsigned long long)st.reads, (unsigned long long)st.fragments, (unsigned long long)st.fastq_bytes,
             (unsigned long long)st.windows, (unsigned long long)st.segments, (unsigned long long)st.batches, st.t_load,
             st.t_engine, st.t_reference,
             st.t_haplotypes, st.t_plan, st.t_sample, st.t_hap_device, st.t_plan_api, st.t_fetch, st.t_write, st.t_total, st.kernel_ms[0], st.kernel_ms[1],
             st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], (unsigned long long)st.queued_items,
-            (unsigned long long)st.requeued_batches);
+            (unsigned long long)st.requeued_batches, st.t_compress, (unsigned long long)st.gz_bytes);
   return 0;
 }

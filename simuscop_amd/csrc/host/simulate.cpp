@@ -43,8 +43,11 @@ struct Engine {  // RAII around sg_ctx, turns status codes into simu::Error
 struct Sink {  // FASTQ output: <output>/<stem>_1.fq + _2.fq, or <stem>.fq (Genome.cpp:857-866)
   FILE* f1 = nullptr;
   FILE* f2 = nullptr;
-  void open(const std::string& dir, const std::string& stem, bool paired, const std::string& suffix) {
+  bool bgzf = false;
+  void open(const std::string& dir, const std::string& stem, bool paired, const std::string& suffix0, bool gz = false) {
     close();
+    bgzf = gz;
+    const std::string suffix = (gz ? ".gz" : "") + suffix0;
     if (paired) {
       std::string a = dir + "/" + stem + "_1.fq" + suffix, b = dir + "/" + stem + "_2.fq" + suffix;
       f1 = fopen(a.c_str(), "wb");
@@ -58,6 +61,12 @@ struct Sink {  // FASTQ output: <output>/<stem>_1.fq + _2.fq, or <stem>.fq (Geno
     }
   }
   void close() {
+    if (bgzf) {  // BGZF end-of-file marker
+      uint8_t eof[28];
+      sg_bgzf_eof(eof);
+      if (f1) fwrite(eof, 1, 28, f1);
+      if (f2) fwrite(eof, 1, 28, f2);
+    }
     if (f1) fclose(f1);
     if (f2) fclose(f2);
     f1 = f2 = nullptr;
@@ -354,7 +363,16 @@ struct Driver {
     st.fragments += nf;
     st.reads += paired ? 2 * nf : nf;
     st.fastq_bytes += n1 + n2;
-    if (opt.write_files || opt.fetch) drain(n1, n2, sink);
+    if (opt.gzip && (opt.write_files || opt.fetch)) {
+      auto tc = Clock::now();
+      uint64_t g1 = 0, g2 = 0;
+      eng.check(sg_compress(eng.ctx, &g1, &g2), "sg_compress");
+      st.t_compress += since(tc);
+      st.gz_bytes += g1 + g2;
+      drain(g1, g2, sink, true);
+    } else if (opt.write_files || opt.fetch) {
+      drain(n1, n2, sink, false);
+    }
   }
 
   // FASTQ sink (the reference's SeqWriter::write, lib/seqwriter/SeqWriter.cpp:41-54): D2H in pinned
@@ -362,7 +380,7 @@ struct Driver {
   // Mate 1 and mate 2 text are independent byte streams into their own files, so pair order is kept.
   static constexpr size_t kChunk = 64u << 20;
   void* pinned[2] = {nullptr, nullptr};
-  void drain(uint64_t n1, uint64_t n2, Sink& sink) {
+  void drain(uint64_t n1, uint64_t n2, Sink& sink, bool compressed) {
     for (void*& b : pinned)
       if (!b) eng.check(sg_host_alloc(eng.ctx, kChunk, &b), "sg_host_alloc");
     struct Job { FILE* f; const char* p; size_t n; };
@@ -394,7 +412,8 @@ struct Driver {
       FILE* f = opt.write_files ? (mate ? sink.f2 : sink.f1) : nullptr;
       for (uint64_t off = 0; off < total; off += kChunk) {
         const size_t n = (size_t)std::min<uint64_t>(kChunk, total - off);
-        int rc = sg_fetch_range(eng.ctx, mate, off, n, (char*)pinned[cur]);  // overlaps the writer's fwrite
+        int rc = compressed ? sg_fetch_compressed(eng.ctx, mate, off, n, pinned[cur])
+                            : sg_fetch_range(eng.ctx, mate, off, n, (char*)pinned[cur]);  // overlaps the writer's fwrite
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&]() { return !have; });  // the other buffer is free again
         if (rc != SG_OK) { stop = true; cv.notify_all(); lk.unlock(); writer.join(); eng.check(rc, "sg_fetch_range"); }
@@ -463,7 +482,7 @@ struct Driver {
     const std::string suffix = opt.shard_world > 1 ? ".part" + std::to_string(opt.shard_rank) : "";
     Sink sink;
     if (genome.mix_props.empty()) {
-      if (opt.write_files) sink.open(out_dir, popus[0], paired, suffix);
+      if (opt.write_files) sink.open(out_dir, popus[0], paired, suffix, opt.gzip != 0);
       set_read_counts(popus[0], reads);
       for (const std::string& chr : genome.chromosomes) run_batch(popus[0], chr, sink);
     } else {
@@ -476,7 +495,7 @@ struct Driver {
           snprintf(buf, sizeof buf, i == 0 ? "%s_%.3f" : "+%s_%.3f", popus[i].c_str(), props[i]);
           stem += buf;
         }
-        if (opt.write_files) sink.open(out_dir, stem, paired, suffix);
+        if (opt.write_files) sink.open(out_dir, stem, paired, suffix, opt.gzip != 0);
         for (size_t i = 0; i < popus.size(); i++) {
           const long popu_reads = (long)(reads * props[i] * acn[popus[i]] / w_acn);  // long*float is a float product (Genome.cpp:935)
           set_read_counts(popus[i], popu_reads);

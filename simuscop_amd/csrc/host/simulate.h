@@ -21,6 +21,8 @@ typedef struct simu_options {
   int32_t host_haplotypes; // 1: parse the FASTA and edit haplotype strings on the host, upload them
                            // (sg_upload_haplotypes); 0 (default): stream the file to the device and
                            // assemble the haplotypes there (sg_reference_*, sg_build_haplotypes)
+  int32_t gzip;            // 1: compress the FASTQ text on the device (sg_compress) and write <name>_1.fq.gz ...
+                           // as BGZF (block gzip); what `zcat` gives back is byte for byte the plain file
 } simu_options;
 
 typedef struct simu_stats {
@@ -43,6 +45,8 @@ typedef struct simu_stats {
   double t_reference;      // part of t_load: reference FASTA to its resident form (host strings or device codes)
   double t_hap_device;     // part of t_plan/t_sample: sg_build_haplotypes / sg_upload_haplotypes calls
   double t_plan_api;       // part of t_sample: sg_plan calls (window upload, work buffers)
+  double t_compress;       // sg_compress calls (gzip mode)
+  uint64_t gz_bytes;       // compressed bytes produced (gzip mode)
 } simu_stats;
 
 // Returns 0 on success.  On failure returns the exit code the reference would use and writes the

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "sg_deflate.h"
 #include "sg_device.h"
 #include "sg_tables.h"
 
@@ -36,6 +37,17 @@ void launch_ref_ingest(const uint8_t* raw, uint8_t* codes, const void* contigs, 
 void launch_hap_copy(uint8_t* chains, const uint8_t* ref_codes, const uint8_t* literals, const void* pieces, uint64_t n, hipStream_t s);
 void launch_hap_patch(uint8_t* chains, const void* patches, uint64_t n, hipStream_t s);
 void launch_encode_bytes(uint8_t* buf, uint64_t n, hipStream_t s);
+// sg_deflate.hip
+struct DevDeflate {
+  const uint8_t* text; uint64_t bytes; uint32_t n_chunks;
+  const uint32_t* code; const uint32_t* prefix; uint32_t prefix_words, prefix_bits;
+  const uint32_t* crc_tab; const uint32_t* crc_shift; uint32_t crc_init_full, crc_init_last;
+  uint32_t* msize; const uint64_t* moff; uint8_t* out;
+};
+void launch_gz_hist(const uint8_t* text, uint64_t bytes, unsigned long long* hist, hipStream_t s);
+void launch_gz_size(const void* d, uint32_t n_chunks, hipStream_t s);
+void launch_gz_encode(const void* d, uint32_t n_chunks, uint32_t prefix_bits, hipStream_t s);
+void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* out, uint64_t* total, hipStream_t s);
 }  // namespace sg
 
 namespace {
@@ -71,7 +83,9 @@ struct sg_ctx {
   sg::DevProfile P{};
   sg::DevBatch B{};
   DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
-      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work;
+      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work, gz1, gz2, gz_work;
+  uint64_t gz_bytes[2] = {0, 0};
+  bool gz_valid = false;
   uint64_t ref_raw_bytes = 0;
   std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
@@ -139,7 +153,7 @@ void sg_destroy(sg_ctx* ctx) {
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
                     &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq,
-                    &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work})
+                    &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work, &ctx->gz1, &ctx->gz2, &ctx->gz_work})
     b->release();
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
@@ -322,6 +336,112 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   }
   ctx->have_profile = true;
   ctx->have_plan = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-gzip sink (kernels: sg_deflate.hip, code construction: sg_deflate.cpp)
+// ------------------------------------------------------------------------------------------------
+int sg_bgzf_eof(uint8_t out[28]) {
+  static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!out) return SG_ERR_INVALID;
+  memcpy(out, eof, 28);
+  return SG_OK;
+}
+
+uint32_t sg_deflate_plan(const uint64_t counts[256], uint8_t lens[257], uint32_t codes[257], uint32_t* prefix_words, uint32_t cap) {
+  if (!counts || !lens || !codes || !prefix_words) return 0;
+  sg::DeflatePlan plan;
+  sg::deflate_build_plan(counts, &plan);
+  if (plan.prefix.size() > cap) return 0;
+  memcpy(lens, plan.lit_len, 257);
+  memcpy(codes, plan.lit_code, 257 * 4);
+  memcpy(prefix_words, plan.prefix.data(), plan.prefix.size() * 4);
+  return plan.prefix_bits;
+}
+
+int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
+  if (!ctx) return SG_ERR_INVALID;
+  if (!ctx->results_valid) return ctx->fail(SG_ERR_INVALID, "sg_compress: call sg_result first");
+  SG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int nm = ctx->B.paired ? 2 : 1;
+  ctx->gz_bytes[0] = ctx->gz_bytes[1] = 0;
+  for (int m = 0; m < nm; m++) {
+    const uint64_t bytes = ctx->host_totals[m];
+    if (!bytes) continue;
+    if (bytes / sg::kGzChunk >= 0xFFFFFFF0ull) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_compress: text too large");
+    const uint8_t* text = m == 0 ? ctx->out1.as<uint8_t>() : ctx->out2.as<uint8_t>();
+    const uint32_t n_chunks = (uint32_t)((bytes + sg::kGzChunk - 1) / sg::kGzChunk);
+    // work buffer: hist[256] u64 | total u64 | tables | msize[n] u32 | moff[n] u64 | block sums
+    const size_t tab_words = 260 + 1024 + sg::kGzLevels * 32 + 256;  // + prefix (<= 256 words)
+    const size_t off_tab = 2048 + 64, off_msize = off_tab + tab_words * 4;
+    const size_t off_moff = (off_msize + (size_t)n_chunks * 4 + 63) & ~(size_t)63;
+    const size_t off_bsum = off_moff + (size_t)n_chunks * 8;
+    SG_ENSURE(ctx->gz_work, off_bsum + ((size_t)sg::scan_blocks(n_chunks) + 8) * 8);
+    uint8_t* wk = ctx->gz_work.as<uint8_t>();
+    // 1. sampled histogram -> Huffman code, member prefix, CRC tables (host)
+    SG_HIP(hipMemsetAsync(wk, 0, 2048 + 64, s));
+    sg::launch_gz_hist(text, bytes, (unsigned long long*)wk, s);
+    SG_HIP(hipGetLastError());
+    uint64_t hist[256];
+    SG_HIP(hipMemcpyAsync(hist, wk, sizeof hist, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipStreamSynchronize(s));
+    sg::DeflatePlan plan;
+    sg::deflate_build_plan(hist, &plan);
+    if (plan.prefix.size() > 256) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_compress: block header longer than expected");
+    std::vector<uint32_t> tab(tab_words, 0);
+    for (int i = 0; i < 257; i++) tab[i] = plan.lit_code[i] | ((uint32_t)plan.lit_len[i] << 16);
+    memcpy(&tab[260], plan.crc_table, sizeof plan.crc_table);
+    memcpy(&tab[260 + 1024], plan.crc_shift, sizeof plan.crc_shift);
+    memcpy(&tab[260 + 1024 + sg::kGzLevels * 32], plan.prefix.data(), plan.prefix.size() * 4);
+    SG_HIP(hipMemcpyAsync(wk + off_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    sg::DevDeflate D;
+    D.text = text; D.bytes = bytes; D.n_chunks = n_chunks;
+    D.code = (const uint32_t*)(wk + off_tab);
+    D.crc_tab = D.code + 260;
+    D.crc_shift = D.crc_tab + 1024;
+    D.prefix = D.crc_shift + sg::kGzLevels * 32;
+    D.prefix_words = (uint32_t)plan.prefix.size();
+    D.prefix_bits = plan.prefix_bits;
+    D.crc_init_full = plan.crc_init_full;
+    const uint64_t last = bytes - (uint64_t)(n_chunks - 1) * sg::kGzChunk;
+    D.crc_init_last = sg::crc_advance(plan, 0xFFFFFFFFu, last);
+    D.msize = (uint32_t*)(wk + off_msize);
+    D.moff = (const uint64_t*)(wk + off_moff);
+    D.out = nullptr;
+    // 2. member sizes -> offsets
+    sg::launch_gz_size(&D, n_chunks, s);
+    sg::launch_scan_u32(D.msize, n_chunks, (uint64_t*)(wk + off_bsum), (uint64_t*)(wk + off_moff), (uint64_t*)(wk + 2048), s);
+    SG_HIP(hipGetLastError());
+    uint64_t total = 0;
+    SG_HIP(hipMemcpyAsync(&total, wk + 2048, 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipStreamSynchronize(s));
+    DevBuf& gz = m == 0 ? ctx->gz1 : ctx->gz2;
+    SG_ENSURE(gz, total + 64);
+    D.out = gz.as<uint8_t>();
+    // 3. encode
+    sg::launch_gz_encode(&D, n_chunks, plan.prefix_bits, s);
+    SG_HIP(hipGetLastError());
+    SG_HIP(hipStreamSynchronize(s));  // tab / plan are host-owned
+    ctx->gz_bytes[m] = total;
+  }
+  ctx->gz_valid = true;
+  if (gz_bytes_r1) *gz_bytes_r1 = ctx->gz_bytes[0];
+  if (gz_bytes_r2) *gz_bytes_r2 = ctx->gz_bytes[1];
+  return SG_OK;
+}
+
+int sg_fetch_compressed(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, void* host_dst) {
+  if (!ctx || mate < 0 || mate > 1 || (bytes && !host_dst)) return SG_ERR_INVALID;
+  if (!ctx->gz_valid || !ctx->results_valid) return ctx->fail(SG_ERR_INVALID, "sg_fetch_compressed: call sg_compress first");
+  if (offset + bytes > ctx->gz_bytes[mate]) return ctx->fail(SG_ERR_INVALID, "sg_fetch_compressed: range past the end of the compressed text");
+  SG_HIP(hipSetDevice(ctx->device));
+  if (bytes) {
+    const uint8_t* src = (mate == 0 ? ctx->gz1.as<uint8_t>() : ctx->gz2.as<uint8_t>()) + offset;
+    SG_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SG_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return SG_OK;
 }
 
@@ -677,6 +797,7 @@ static int run_pass(sg_ctx* ctx) {
   SG_HIP(hipGetLastError());
   ctx->sampled = true;
   ctx->results_valid = false;
+  ctx->gz_valid = false;
   return SG_OK;
 }
 

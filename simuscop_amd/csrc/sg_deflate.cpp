@@ -1,0 +1,172 @@
+// sg_deflate.cpp -- see sg_deflate.h: Huffman code construction, the DEFLATE dynamic-block header
+// (RFC 1951 section 3.2.7), the BGZF member prefix and the CRC-32 tables for the block-gzip sink.
+#include "sg_deflate.h"
+
+#include <algorithm>
+#include <cstring>
+#include <queue>
+
+namespace sg {
+
+namespace {
+
+// Code lengths (0 for unused symbols) of a complete prefix code with no length above `maxbits`.
+void limited_lengths(const uint64_t* freq, int n, int maxbits, uint8_t* len) {
+  std::memset(len, 0, (size_t)n);
+  std::vector<int> used;
+  for (int i = 0; i < n; i++)
+    if (freq[i]) used.push_back(i);
+  if (used.empty()) return;
+  if (used.size() == 1) {  // a complete code needs two leaves: pair the symbol with a neighbour
+    len[used[0]] = 1;
+    len[used[0] == 0 ? 1 : used[0] - 1] = 1;
+    return;
+  }
+  // Huffman tree: nodes 0..n-1 are leaves, parents appended
+  struct Node { uint64_t w; int id; };
+  auto cmp = [](const Node& a, const Node& b) { return a.w > b.w || (a.w == b.w && a.id > b.id); };
+  std::priority_queue<Node, std::vector<Node>, decltype(cmp)> heap(cmp);
+  std::vector<int> parent((size_t)n + used.size(), -1);
+  for (int i : used) heap.push(Node{freq[i], i});
+  int next = n;
+  while (heap.size() > 1) {
+    Node a = heap.top(); heap.pop();
+    Node b = heap.top(); heap.pop();
+    parent[a.id] = parent[b.id] = next;
+    heap.push(Node{a.w + b.w, next});
+    next++;
+  }
+  for (int i : used) {
+    int d = 0;
+    for (int v = i; parent[v] >= 0; v = parent[v]) d++;
+    len[i] = (uint8_t)std::min(d, maxbits);
+  }
+  // Kraft sum in units of 2^-maxbits: lengthen the deepest codes that still can grow until the code
+  // fits, then hand any slack back by shortening the most frequent codes of maximal length.
+  const uint64_t full = 1ull << maxbits;
+  auto kraft = [&]() { uint64_t k = 0; for (int i : used) k += full >> len[i]; return k; };
+  uint64_t k = kraft();
+  while (k > full) {
+    int best = -1;
+    for (int i : used)
+      if (len[i] < maxbits && (best < 0 || len[i] > len[best] || (len[i] == len[best] && freq[i] < freq[best]))) best = i;
+    k -= full >> (len[best] + 1);
+    len[best]++;
+  }
+  while (k < full) {  // only after the loop above ran: symbols at maxbits exist
+    int best = -1;
+    for (int i : used)
+      if (len[i] == maxbits && (best < 0 || freq[i] > freq[best])) best = i;
+    if (best < 0) break;
+    len[best]--;
+    k += 1;
+  }
+}
+
+uint32_t reverse_bits(uint32_t v, int n) {
+  uint32_t r = 0;
+  for (int i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1 - i);
+  return r;
+}
+
+// canonical codes (RFC 1951 3.2.2), returned bit-reversed
+void canonical_codes(const uint8_t* len, int n, uint32_t* code) {
+  uint32_t bl_count[16] = {0}, next_code[16] = {0};
+  for (int i = 0; i < n; i++) bl_count[len[i]]++;
+  bl_count[0] = 0;
+  uint32_t c = 0;
+  for (int b = 1; b < 16; b++) { c = (c + bl_count[b - 1]) << 1; next_code[b] = c; }
+  for (int i = 0; i < n; i++) code[i] = len[i] ? reverse_bits(next_code[len[i]]++, len[i]) : 0;
+}
+
+struct BitWriter {
+  std::vector<uint32_t> w;
+  uint32_t bits = 0;
+  void put(uint32_t v, int n) {  // n <= 24, LSB first
+    for (int i = 0; i < n; i++) {
+      if ((bits & 31u) == 0) w.push_back(0);
+      w.back() |= ((v >> i) & 1u) << (bits & 31u);
+      bits++;
+    }
+  }
+};
+
+}  // namespace
+
+uint32_t crc_advance(const DeflatePlan& plan, uint32_t state, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) state = (state >> 8) ^ plan.crc_table[0][state & 0xFFu];
+  return state;
+}
+
+void deflate_build_plan(const uint64_t counts[256], DeflatePlan* plan) {
+  // ---- literal / length code: every byte value and end-of-block present ----
+  uint64_t freq[257];
+  uint64_t total = 0;
+  for (int i = 0; i < 256; i++) { freq[i] = counts[i] + 1; total += freq[i]; }
+  freq[256] = std::max<uint64_t>(1, total / kGzChunk);  // one end-of-block per member
+  limited_lengths(freq, 257, 15, plan->lit_len);
+  canonical_codes(plan->lit_len, 257, plan->lit_code);
+
+  // ---- code-length sequence: 257 literal/length lengths + one distance code of zero bits (literals only) ----
+  std::vector<uint8_t> seq(plan->lit_len, plan->lit_len + 257);
+  seq.push_back(0);
+  struct Tok { uint8_t sym, extra, extra_bits; };
+  std::vector<Tok> toks;
+  for (size_t i = 0; i < seq.size();) {
+    size_t j = i;
+    while (j < seq.size() && seq[j] == seq[i]) j++;
+    size_t run = j - i;
+    if (seq[i] == 0) {
+      while (run >= 11) { size_t r = std::min<size_t>(run, 138); toks.push_back(Tok{18, (uint8_t)(r - 11), 7}); run -= r; }
+      if (run >= 3) { toks.push_back(Tok{17, (uint8_t)(run - 3), 3}); run = 0; }
+      while (run--) toks.push_back(Tok{0, 0, 0});
+    } else {
+      toks.push_back(Tok{seq[i], 0, 0});
+      run--;
+      while (run >= 3) { size_t r = std::min<size_t>(run, 6); toks.push_back(Tok{16, (uint8_t)(r - 3), 2}); run -= r; }
+      while (run--) toks.push_back(Tok{seq[i], 0, 0});
+    }
+    i = j;
+  }
+  uint64_t cl_freq[19] = {0};
+  for (const Tok& t : toks) cl_freq[t.sym]++;
+  uint8_t cl_len[19];
+  uint32_t cl_code[19];
+  limited_lengths(cl_freq, 19, 7, cl_len);
+  canonical_codes(cl_len, 19, cl_code);
+  static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  int hclen = 19;
+  while (hclen > 4 && cl_len[order[hclen - 1]] == 0) hclen--;
+
+  // ---- member prefix: gzip header with the BGZF extra field, then the block header ----
+  BitWriter bw;
+  static const uint8_t head[kGzMemberHeader] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};  // BSIZE filled per member
+  for (uint8_t b : head) bw.put(b, 8);
+  bw.put(1, 1);            // BFINAL
+  bw.put(2, 2);            // BTYPE = dynamic Huffman
+  bw.put(0, 5);            // HLIT: 257 literal/length codes
+  bw.put(0, 5);            // HDIST: 1 distance code
+  bw.put((uint32_t)(hclen - 4), 4);
+  for (int i = 0; i < hclen; i++) bw.put(cl_len[order[i]], 3);
+  for (const Tok& t : toks) {
+    bw.put(cl_code[t.sym], cl_len[t.sym]);
+    if (t.extra_bits) bw.put(t.extra, t.extra_bits);
+  }
+  plan->prefix = bw.w;
+  plan->prefix_bits = bw.bits;
+
+  // ---- CRC-32 ----
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    plan->crc_table[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; i++)
+    for (int t = 1; t < 4; t++)
+      plan->crc_table[t][i] = (plan->crc_table[t - 1][i] >> 8) ^ plan->crc_table[0][plan->crc_table[t - 1][i] & 0xFFu];
+  for (uint32_t k = 0; k < kGzLevels; k++)
+    for (int j = 0; j < 32; j++) plan->crc_shift[k][j] = crc_advance(*plan, 1u << j, (uint64_t)kGzLaneBytes << k);
+  plan->crc_init_full = crc_advance(*plan, 0xFFFFFFFFu, kGzChunk);
+}
+
+}  // namespace sg

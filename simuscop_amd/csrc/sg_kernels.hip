@@ -1248,6 +1248,14 @@ void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s) {
   hipLaunchKernelGGL(scan_sums_kernel, dim3(nm), dim3(1024), 0, s, bsum, nblk, B.totals);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk, nm), dim3(SCAN_BLOCK), 0, s, B.reclen, B.n_slots, bsum, nblk, B.recoff);
 }
+// exclusive scan of n u32 values into u64 offsets (one row); total -> *total
+void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* out, uint64_t* total, hipStream_t s) {
+  if (!n) return;
+  const uint32_t nblk = scan_blocks(n);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk, 1), dim3(SCAN_BLOCK), 0, s, in, n, bsum, nblk);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, total);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk, 1), dim3(SCAN_BLOCK), 0, s, in, n, bsum, nblk, out);
+}
 // LDS budget of emit_kernel: tables that fit are staged, the rest is read through L2.
 static const size_t kLdsBytes = 160 * 1024;
 template <int KT, int QLG, bool SL, bool QL>
