@@ -201,22 +201,31 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     if (4 * c + 3 < j) continue;  // all four positions were consumed by a deletion
     uint32_t x[4];
     philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
-    // 99.5 % of the calls end here: no position whose high half reaches a threshold's high half
-    bool cand = false;
+    // 99.5 % of a lane's calls have no position whose high half reaches a threshold's high half; a wave
+    // (64 reads) has one in about a quarter of its calls, almost always a real event.  Only the positions
+    // some lane flagged are walked, and the low halves are fetched only by a lane whose high half EQUALS
+    // a threshold's (2 in 65536).
+    bool cand[4];
+    bool any = false;
 #pragma unroll
-    for (int h = 0; h < 4; h++) cand |= (x[h] >> 16) <= ThiI || (x[h] & 0xFFFFu) <= ChiD;
-    if (!cand) continue;
-    uint32_t y[4];
-    philox4x32_10(t + B.slot_offset, (uint32_t)c, 1, c3, B.k0, B.k1, y);
-#pragma unroll 1
     for (int h = 0; h < 4; h++) {
+      cand[h] = (x[h] >> 16) <= ThiI || (x[h] & 0xFFFFu) <= ChiD;
+      any |= cand[h];
+    }
+    if (__ballot(any) == 0ull) continue;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      if (__ballot(cand[h]) == 0ull) continue;
       const int jj = 4 * c + h;
-      if (jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
-      const uint32_t xw = h == 0 ? x[0] : h == 1 ? x[1] : h == 2 ? x[2] : x[3];
-      const uint32_t yw = h == 0 ? y[0] : h == 1 ? y[1] : h == 2 ? y[2] : y[3];
-      const uint32_t hi_i = xw >> 16, hi_d = xw & 0xFFFFu;
-      const bool is_ins = hi_i < ThiI || (hi_i == ThiI && (yw >> 16) <= TloI);
-      const bool is_del = hi_d < ChiD || (hi_d == ChiD && (yw & 0xFFFFu) < CloD);
+      if (!cand[h] || jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
+      const uint32_t hi_i = x[h] >> 16, hi_d = x[h] & 0xFFFFu;
+      bool is_ins = hi_i < ThiI, is_del = hi_d < ChiD;
+      if (hi_i == ThiI || hi_d == ChiD) {
+        uint32_t y[4];
+        philox4x32_10(t + B.slot_offset, (uint32_t)c, 1, c3, B.k0, B.k1, y);
+        if (hi_i == ThiI) is_ins = (y[h] >> 16) <= TloI;
+        if (hi_d == ChiD) is_del = (y[h] & 0xFFFFu) < CloD;
+      }
       if (is_ins) {
         uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
