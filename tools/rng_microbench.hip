@@ -4,6 +4,22 @@
 #include <cstdint>
 #include <vector>
 
+// the production form (sg_kernels.hip): v_mad_u64_u32 products, three-input xor in one v_bitop3_b32
+__device__ __forceinline__ void philox_prod(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+    c1 = lo1;
+    c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+    c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
 template <int ROUNDS, bool MAD64>
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -47,6 +63,7 @@ __global__ __launch_bounds__(256) void bench(uint32_t* out, int iters, uint32_t 
     if (V == 2) philox<7, true>(t, i, 0, 6, k0, k1, o);
     if (V == 3) threefry4x32<20>(t, i, 0, 6, k0, k1, o);
     if (V == 4) threefry4x32<12>(t, i, 0, 6, k0, k1, o);
+    if (V == 5) philox_prod(t, i, 0, 6, k0, k1, o);
     acc ^= o[0] + o[1] + o[2] + o[3];
   }
   out[t] = acc;
@@ -56,8 +73,8 @@ int main() {
   const int blocks = 256 * 8, iters = 2000;
   uint32_t* d; hipMalloc(&d, blocks * 256 * 4);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  const char* names[] = {"philox4x32-10 mul_lo+mul_hi", "philox4x32-10 mad_u64_u32", "philox4x32-7 mad_u64", "threefry4x32-20", "threefry4x32-12"};
-  for (int v = 0; v < 5; v++) {
+  const char* names[] = {"philox4x32-10 mul_lo+mul_hi", "philox4x32-10 mad_u64_u32", "philox4x32-7 mad_u64", "threefry4x32-20", "threefry4x32-12", "philox4x32-10 mad_u64 + bitop3"};
+  for (int v = 0; v < 6; v++) {
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(a);
       if (v == 0) hipLaunchKernelGGL(bench<0>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, 2u);
@@ -65,6 +82,7 @@ int main() {
       if (v == 2) hipLaunchKernelGGL(bench<2>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, 2u);
       if (v == 3) hipLaunchKernelGGL(bench<3>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, 2u);
       if (v == 4) hipLaunchKernelGGL(bench<4>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, 2u);
+      if (v == 5) hipLaunchKernelGGL(bench<5>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, 2u);
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       double calls = (double)blocks * 256 * iters;
