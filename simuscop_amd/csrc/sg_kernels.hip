@@ -1054,43 +1054,40 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const uint32_t nmain = (n_fast + RPI - 1u) / RPI;
     unsigned long long more = __ballot(items > TI && nev_l < 2u);
     uint32_t cb = TI;
-    for (uint32_t step = 0;; step++) {
-      const bool done = step >= nmain && !more;
-      if (done || nslow > SLOW_CAP - 64u) {
-        if (nslow) flush_slow();
-        if (done) break;
-      }
-      uint32_t r, c;
-      bool ok;
-      uint32_t o0 = hoff0, a0 = hw0, k0_ = hk0, o1 = hoff1, a1 = hw1, k1_ = hk1;
-      if (step < nmain) {
-        const uint32_t ri = step * RPI + sub;
-        c = c_lane;
-        ok = lane_ok && ri < n_fast;
-        r = perm[ok ? ri : step * RPI];
-      } else {
-        r = (uint32_t)__builtin_ctzll(more);
-        c = cb + lane;   // items past the fixed map are never the first item of a read
-        ok = true;
-        o0 = 6u; a0 = 6u; k0_ = 20u; o1 = 8u; a1 = 6u; k1_ = 20u;
-      }
-      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-      const uint32_t np = m1.y & 0xFFFFu;
-      const uint32_t nitems = (np + 7u) / 8u;
-      if (step >= nmain) {
-        cb += 64u;
-        if (cb >= nitems) { more &= more - 1ull; cb = TI; }
-      }
+    // one item per lane; windows with a non-ACGT base (or, DIAG, a substitution) are queued for the
+    // generic code.  Two call sites -- the fixed map and the long-read tail -- so that the per-lane
+    // context constants of the fixed map stay loop-invariant registers.
+    auto run_item = [&](uint32_t r, uint32_t c, bool ok, const uint4 m0, const uint4 m1, uint32_t o0, uint32_t a0, uint32_t k0_,
+                        uint32_t o1, uint32_t a1, uint32_t k1_, uint32_t c_idle) {
+      const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
-      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : (step < nmain ? c : 1u),
-                                          active, o0, a0, k0_, o1, a1, k1_, tail_rows + r);
-      // windows with a non-ACGT base / reads with >= 2 indels: queue (read, item) for the generic code
+      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
+                                          o1, a1, k1_, tail_rows + r);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
         nslow += (uint32_t)__popcll(sm);
       }
+    };
+    for (uint32_t step = 0; step < nmain; step++) {  // fixed lane -> (read, item) map
+      if (nslow > SLOW_CAP - 64u) flush_slow();
+      const uint32_t ri = step * RPI + sub;
+      const bool ok = lane_ok && ri < n_fast;
+      const uint32_t r = perm[ok ? ri : step * RPI];
+      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+      run_item(r, c_lane, ok, m0, m1, hoff0, hw0, hk0, hoff1, hw1, hk1, c_lane);
     }
+    while (more) {  // items past the fixed map (reads grown by insertions, reads of more than 64 items): never a first item
+      if (nslow > SLOW_CAP - 64u) flush_slow();
+      const uint32_t r = (uint32_t)__builtin_ctzll(more);
+      const uint32_t c = cb + lane;
+      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+      const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
+      cb += 64u;
+      if (cb >= nitems) { more &= more - 1ull; cb = TI; }
+      run_item(r, c, true, m0, m1, 6u, 6u, 20u, 8u, 6u, 20u, 1u);
+    }
+    if (nslow) flush_slow();
     // ---- per-read pass, lane = read: header text, last partial item, record separators ----
     // These byte-granular stores touch lines the steps above have just written from this wave, so
     // they merge in L2.  Reads whose last item went to the generic code (0xFFFFFFFF row) get only the
