@@ -221,6 +221,10 @@ int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
  * their queue overflowed so that the whole batch was emitted again by the generic kernel.  Results
  * are identical either way (Profile::predict, Profile.cpp:1520-1650 has one code path).          */
 int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
+/* Which emit kernel the loaded profile gets (after sg_load_profile): 0 generic (tables that do not fit
+ * LDS, k-mer sizes other than 3), 1 straight-line kernel with the whole quality table in LDS,
+ * 2 straight-line kernel with the (reference == called) quality rows in LDS (wide quality alphabets). */
+int sg_emit_variant(sg_ctx* ctx);
 
 /* Exact u32 form of the reference's inverse-CDF draw, exposed for tests: number of 32-bit draws
  * x for which randIndx's `r <= c` holds (r = 2.2204e-16 + (1-2.2204e-16)*x/2^32).               */

@@ -24,7 +24,7 @@ ENGINE_SYMBOLS = [
     "sg_upload_haplotypes", "sg_reference_begin", "sg_reference_chunk", "sg_sync", "sg_reference_scan",
     "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_compress", "sg_fetch_compressed",
     "sg_bgzf_eof", "sg_deflate_plan", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
-    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
+    "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_host_free",
 ]
 
@@ -133,6 +133,7 @@ def load_engine():
     lib.sg_set_profiling.argtypes = [vp, C.c_int]
     lib.sg_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
     lib.sg_emit_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    lib.sg_emit_variant.argtypes = [vp]
     lib.sg_cdf_count_le.argtypes = [C.c_double]
     lib.sg_cdf_count_le.restype = C.c_uint64
     _engine = lib

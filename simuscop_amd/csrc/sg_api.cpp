@@ -25,6 +25,7 @@ void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main);
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
+int emit_variant(const DevProfile& P);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
 // sg_haplotypes.hip
@@ -799,6 +800,11 @@ static int run_pass(sg_ctx* ctx) {
   ctx->results_valid = false;
   ctx->gz_valid = false;
   return SG_OK;
+}
+
+int sg_emit_variant(sg_ctx* ctx) {
+  if (!ctx || !ctx->have_profile) return -1;
+  return sg::emit_variant(ctx->P);
 }
 
 int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued) {

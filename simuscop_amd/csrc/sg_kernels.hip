@@ -919,7 +919,12 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
         __builtin_memcpy(qo, &Q, 8);
       }
     } else {
-      *tail_row = make_uint4(slow ? 0xFFFFFFFFu : sw[0], sw[1], qw[0], qw[1]);  // base characters are never 0xFF
+      // parked in the read's own LDS row, over the fields no lane needs once the last item has been
+      // sampled (fragment offset, 2^32/n', event): base characters are never 0xFF
+      tail_row[0].x = slow ? 0xFFFFFFFFu : sw[0];
+      tail_row[0].y = sw[1];
+      tail_row[1].z = qw[0];
+      tail_row[1].w = qw[1];
     }
   }
   return slow;
@@ -947,8 +952,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint32_t* lds_qual = (uint32_t*)(smem + sub_rows);
   uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
-  uint4* tail_all = (uint4*)(slow_all + EMIT_WAVES * SLOW_CAP);
-  uint8_t* perm_all = (uint8_t*)(tail_all + EMIT_WAVES * 64);
+  uint8_t* perm_all = (uint8_t*)(slow_all + EMIT_WAVES * SLOW_CAP);
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   // staging with the fast kernel's digit / base-order permutations
   for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
@@ -973,7 +977,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   __syncthreads();
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
-  uint4* tail_rows = tail_all + wv * 64;
   uint8_t* perm = perm_all + wv * 64;
 
   const uint32_t G = RPI * (64u / RPI);
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         if (lane < cnt) slow_list[nslow + lane] = rr | ((c0 + lane) << 8);
         nslow += cnt;
       }
-      if (lane == 0u) tail_rows[rr].x = 0xFFFFFFFFu;  // its last item is not in a tail row
+      if (lane == 0u) meta_rows[rr * 2].x = 0xFFFFFFFFu;  // its last item is not parked in the row
     }
     wave_lds_sync();
     const uint32_t nmain = (n_fast + RPI - 1u) / RPI;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
       const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
-                                          o1, a1, k1_, tail_rows + r);
+                                          o1, a1, k1_, meta_rows + r * 2);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           if (rem == 16u) __builtin_memcpy(q, &part, 16);
           else store_var(q, ((uint64_t)part.y << 32) | part.x, ((uint64_t)part.w << 32) | part.z, rem);
         }
-        const uint4 tr = tail_rows[lane];
+        const uint4 tr = make_uint4(r0.x, r0.y, r1.z, r1.w);  // the parked last item (fast_item)
         const uint32_t d = (tr.x != 0xFFFFFFFFu) ? (np & 7u) : 0u;  // bases (and qualities) of the partial item
         const uint64_t S = ((uint64_t)tr.y << 32) | tr.x, Q = ((uint64_t)tr.w << 32) | tr.z;
         const uint64_t keep = (1ull << (8u * d)) - 1ull;
@@ -1278,8 +1281,7 @@ static EmitLds emit_lds(const DevProfile& P) {
   e.sub_rows = kmer_count * (uint32_t)P.bins;
   e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
   e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 * 16 +
-                       (size_t)EMIT_WAVES * 64;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64;
   const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
   const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
   e.sub_lds = fixed + sub_b <= kLdsBytes;
@@ -1298,6 +1300,7 @@ static int emit_fast_mode(const DevProfile& P) {
   if (P.qual_w <= 64 && e.diag_lds) return 2;
   return 0;
 }
+int emit_variant(const DevProfile& P) { return emit_fast_mode(P); }
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
   (void)B;
   return emit_fast_mode(P) != 0;

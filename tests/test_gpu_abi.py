@@ -150,3 +150,20 @@ def test_pass_is_a_pure_function_of_the_seed(c2_session):
     c = _head(sess, 8 << 20)
     assert c[2] == a[2]                      # the plan (counts) does not depend on the sampling seed ...
     assert c[3] != a[3] and c[4] != a[4]     # ... the reads do
+
+
+@pytest.mark.parametrize("prof,want", [("xten", 1), ("hs2500", 2), ("hs2000", 2), ("gaiix", 2)])
+def test_shipped_profiles_get_the_straight_line_emit_kernel(prof, want, tmp_path):
+    """Regression guard on the LDS budget: all four shipped profiles must fit the straight-line kernel
+    (XTen with its whole 8-symbol quality table, the wide-alphabet ones with the diagonal rows)."""
+    fa = str(tmp_path / "ref.fa")
+    synth.write_fasta(fa, [("chr1", 40000)], seed=3)
+    cfg = str(tmp_path / "c.txt")
+    with open(cfg, "w") as f:
+        f.write(f"ref = {fa}\nprofile = {os.path.join(cases.TESTDATA, cases.PROFILES[prof])}\nname = s\noutput = {tmp_path}/o\n"
+                f"layout = PE\nthreads = 1\nverbose = 0\ncoverage = 2\ninsertSize = 300\n")
+    sess = simuscop_amd.Session(cfg, device=0, write_files=0, quiet=1, seed=1)
+    try:
+        assert sess.eng.sg_emit_variant(sess.ctx) == want
+    finally:
+        sess.close()
