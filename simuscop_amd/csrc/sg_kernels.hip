@@ -16,6 +16,7 @@
 //   gc_kernel        calculateGCPercent              (lib/mydefine/MyDefine.cpp:279-303)
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "sg_device.h"
 
@@ -779,7 +780,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..
   return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
 }
 
-template <bool PAIRED, bool DIAG>
+template <bool PAIRED, bool DIAG, bool GUARD>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
                                           const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
@@ -787,11 +788,16 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
-  const uint32_t np = m1.y & 0xFFFFu, nev = (m1.y >> 16) & 0x3Fu, hdr = m1.y >> 22;
+  // GUARD (item-stream map): an idle lane may be looking at a row whose read is finished; its fragment
+  // offset, reciprocal and event word then hold the parked last item (see below), so an idle lane must
+  // not follow them -- it reads a harmless in-bounds window and has no event.  With the fixed map an
+  // idle lane only ever sees rows of reads of its own step, which are still intact when it loads them.
+  const uint32_t np = m1.y & 0xFFFFu, nev = (GUARD && !active) ? 0u : ((m1.y >> 16) & 0x3Fu), hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
   const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
-  const uint8_t* src = flen == 0u ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
+  const bool no_frag = GUARD ? !active : flen == 0u;
+  const uint8_t* src = no_frag ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
 
   // 16 encoded bytes -> byte order by position (reverse reads), complement, validity, 2-bit pack
   auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
@@ -940,9 +946,9 @@ __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, 
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
 
-template <bool PAIRED, bool DIAG>
+template <bool PAIRED, bool DIAG, bool STREAM>
 __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
-                                                                 uint32_t TI, uint32_t RPI) {
+                                                                 uint32_t TI, uint32_t map_arg) {
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
@@ -979,15 +985,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
   uint8_t* perm = perm_all + wv * 64;
 
-  const uint32_t G = RPI * (64u / RPI);
+  // Two lane -> (read, item) maps over the first TI items of a group's reads:
+  //   STREAM  G = 64 reads; their items form one stream, 64 per step: lane l of step s does stream item
+  //           i = 64 s + l = item i % TI of the (i / TI)-th read in step order; every lane busy whatever TI is;
+  //   fixed   RPI = 64 / TI whole reads per step, lane = (read in step, item): constant per lane, cheaper per
+  //           step, but 64 - RPI * TI lanes idle (7 at TI 19).
+  // map_arg = ceil-reciprocal of TI (STREAM) or RPI (fixed).  launch_emit picks by measurement.
+  const uint32_t inv_TI = map_arg, RPI = STREAM ? 1u : map_arg;
+  const uint32_t G = STREAM ? 64u : RPI * (64u / RPI);
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
   const uint32_t sub = lane / TI, c_lane = lane - sub * TI;
   const bool lane_ok = sub < RPI;
   // first item of a read: its first two bases have 1- and 2-base contexts ("XXb", "Xbb")
-  const bool head = c_lane == 0u;
-  const uint32_t hoff0 = head ? 10u : 6u, hw0 = head ? 2u : 6u, hk0 = head ? 0u : 20u;
-  const uint32_t hoff1 = head ? 10u : 8u, hw1 = head ? 4u : 6u, hk1 = head ? 4u : 20u;
-
+  const bool head_f = c_lane == 0u;
+  const uint32_t hoff0 = head_f ? 10u : 6u, hw0 = head_f ? 2u : 6u, hk0 = head_f ? 0u : 20u;
+  const uint32_t hoff1 = head_f ? 10u : 8u, hw1 = head_f ? 4u : 6u, hk1 = head_f ? 4u : 20u;
   for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
@@ -1054,7 +1066,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       if (lane == 0u) meta_rows[rr * 2].x = 0xFFFFFFFFu;  // its last item is not parked in the row
     }
     wave_lds_sync();
-    const uint32_t nmain = (n_fast + RPI - 1u) / RPI;
+    const uint32_t n_items = n_fast * TI, nmain = STREAM ? (n_items + 63u) / 64u : (n_fast + RPI - 1u) / RPI;
     unsigned long long more = __ballot(items > TI && nev_l < 2u);
     uint32_t cb = TI;
     // one item per lane; windows with a non-ACGT base (or, DIAG, a substitution) are queued for the
@@ -1064,7 +1076,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
                         uint32_t o1, uint32_t a1, uint32_t k1_, uint32_t c_idle) {
       const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
-      const bool slow = fast_item<PAIRED, DIAG>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
+      const bool slow = fast_item<PAIRED, DIAG, STREAM>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
                                           o1, a1, k1_, meta_rows + r * 2);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
@@ -1072,13 +1084,26 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         nslow += (uint32_t)__popcll(sm);
       }
     };
-    for (uint32_t step = 0; step < nmain; step++) {  // fixed lane -> (read, item) map
-      if (nslow > SLOW_CAP - 64u) flush_slow();
-      const uint32_t ri = step * RPI + sub;
-      const bool ok = lane_ok && ri < n_fast;
-      const uint32_t r = perm[ok ? ri : step * RPI];
-      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-      run_item(r, c_lane, ok, m0, m1, hoff0, hw0, hk0, hoff1, hw1, hk1, c_lane);
+    if (STREAM) {
+      for (uint32_t step = 0; step < nmain; step++) {  // the item stream, 64 items per step
+        if (nslow > SLOW_CAP - 64u) flush_slow();
+        const uint32_t i = step * 64u + lane;
+        const bool ok = i < n_items;
+        const uint32_t ri = (i * inv_TI) >> 20, c = i - ri * TI;  // i / TI, i % TI (exact: i * TI < 2^20)
+        const uint32_t r = perm[ok ? ri : 0u];
+        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+        const bool head = c == 0u;
+        run_item(r, c, ok, m0, m1, head ? 10u : 6u, head ? 2u : 6u, head ? 0u : 20u, head ? 10u : 8u, head ? 4u : 6u, head ? 4u : 20u, c);
+      }
+    } else {
+      for (uint32_t step = 0; step < nmain; step++) {  // RPI whole reads per step
+        if (nslow > SLOW_CAP - 64u) flush_slow();
+        const uint32_t ri = step * RPI + sub;
+        const bool ok = lane_ok && ri < n_fast;
+        const uint32_t r = perm[ok ? ri : step * RPI];
+        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
+        run_item(r, c_lane, ok, m0, m1, hoff0, hw0, hk0, hoff1, hw1, hk1, c_lane);
+      }
     }
     while (more) {  // items past the fixed map (reads grown by insertions, reads of more than 64 items): never a first item
       if (nslow > SLOW_CAP - 64u) flush_slow();
@@ -1330,16 +1355,38 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
   if (gx > need) gx = need;
   dim3 grid(gx, nm);
   const int mode = force_generic ? 0 : emit_fast_mode(P);
+  // straight-line kernel, item-stream map by default: measured on the four shipped profiles it ties with the
+  // fixed map on XTen (4.91 vs 4.97 ms) and wins clearly with the diagonal-row variant (7.1 vs 9.2 ms
+  // HiSeq2500, 7.4 vs 10.5 ms HiSeq2000 / GAIIx).  SG_EMIT_MAP=fixed selects the other map (diagnostics).
+  // three bases of slack in TI: a read that gained up to 3 bases still fits the map (a longer one costs a whole
+  // extra step with a single busy lane; at TI = ceil(L/8) that happened for 5 % of the XTen reads)
+  uint32_t TIf = ((uint32_t)P.L + 3u + 7u) / 8u;
+  if (TIf > 64u) TIf = 64u;
+  const uint32_t RPIf = 64u / TIf;
+  bool stream = true;
+  if (const char* e = getenv("SG_EMIT_MAP")) stream = e[0] == 's';
+  const uint32_t Gf = stream ? 64u : RPIf * (64u / RPIf);
+  const uint32_t fneed = ((B.n_slots + Gf - 1u) / Gf + EMIT_WAVES - 1) / EMIT_WAVES;
+  uint32_t fgx = (uint32_t)cus / nm;
+  if (fgx < 1) fgx = 1;
+  if (fgx > fneed) fgx = fneed;
+  const dim3 fgrid(fgx, nm);
+  const uint32_t map_arg = stream ? (1u << 20) / TIf + 1u : RPIf;
   auto launch_fast = [&](auto kern, size_t bytes, uint32_t qwords) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(EMIT_THREADS), bytes, s, P, B, sub_rows, qwords, TI, RPI);
+    hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), bytes, s, P, B, sub_rows, qwords, TIf, map_arg);
+  };
+  auto pick = [&](auto paired_t, auto diag_t, size_t bytes, uint32_t qwords) {
+    constexpr bool PA = decltype(paired_t)::value, DG = decltype(diag_t)::value;
+    if (stream) launch_fast(emit_fast_kernel<PA, DG, true>, bytes, qwords);
+    else launch_fast(emit_fast_kernel<PA, DG, false>, bytes, qwords);
   };
   if (mode == 1) {
-    if (B.paired) launch_fast(emit_fast_kernel<true, false>, lds, qual_words);
-    else launch_fast(emit_fast_kernel<false, false>, lds, qual_words);
+    if (B.paired) pick(std::true_type{}, std::false_type{}, lds, qual_words);
+    else pick(std::false_type{}, std::false_type{}, lds, qual_words);
   } else if (mode == 2) {
-    if (B.paired) launch_fast(emit_fast_kernel<true, true>, e.lds_diag, e.diag_words);
-    else launch_fast(emit_fast_kernel<false, true>, e.lds_diag, e.diag_words);
+    if (B.paired) pick(std::true_type{}, std::true_type{}, e.lds_diag, e.diag_words);
+    else pick(std::false_type{}, std::true_type{}, e.lds_diag, e.diag_words);
   }
   if (mode != 0) {
     if (after_main) (void)hipEventRecord(after_main, s);
