@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,7 +61,12 @@ struct DevBuf {
     if (bytes <= cap) return 0;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
+    static const bool trace = getenv("SG_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (trace)
+      fprintf(stderr, "[sg] hipMalloc %.1f MB: %.2f ms\n", want / 1048576.0,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) { p = nullptr; return (int)e; }
     cap = want;
     return 0;
