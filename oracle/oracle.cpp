@@ -1022,6 +1022,9 @@ struct Genome {
         }
         if (i >= 0) {
           n -= i;
+          // the reference spins forever here when ploidy == 1 (every draw equals k, Segment.cpp:188-197); a
+          // checker that hangs is of no use, so this one input is refused (the GPU host refuses it too)
+          if (n > 0 && ploidy == 1) throw Fail("ERROR: a copy-number gain cannot be placed on a haploid genome (ploidy = 1)");
           while (n > 0) {
             int j = (int)hapRandomInteger(0, ploidy, ctx, segOrd, drawIdx);
             if (j != k) { g.seqReps[j]++; n--; }

@@ -142,6 +142,8 @@ void Genome::choose_haplotypes(Segment& g, uint64_t seed, uint32_t ctx24, uint32
   }
   if (i >= 0) {
     extra -= i;
+    // ploidy 1: every draw equals k and the reference spins forever (Segment.cpp:188-197)
+    if (extra > 0 && ploidy == 1) throw Error("ERROR: a copy-number gain cannot be placed on a haploid genome (ploidy = 1)");
     while (extra > 0) {
       int j = pick();
       if (j != k) { g.seq_reps[j]++; extra--; }

@@ -1,0 +1,64 @@
+"""Seeded random configurations, GPU (C ABI through the CLI) against the oracle in Philox mode, byte for
+byte: contig count and sizes, profile, layout, coverage, insert size, ploidy, variants, SNPs, seed."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import cases
+from simuscop_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMU = os.path.join(ROOT, "simuscop_amd", "lib", "simuReads")
+
+
+def _make(rng, wd):
+    fa = os.path.join(wd, "ref.fa")
+    n_contigs = rng.choice([1, 1, 2, 3, 5])
+    contigs = [("chr%d" % (i + 1), rng.choice([900, 4000, 30000, 90000, 250000, 1200000])) for i in range(n_contigs)]
+    synth.write_fasta(fa, contigs, seed=rng.randrange(1, 1000), line_len=rng.choice([50, 60, 70, 80]),
+                      n_islands=rng.choice([None, None, (5000, 7), (20000, 300)]))
+    prof = rng.choice(list(cases.PROFILES))
+    layout = rng.choice(["PE", "PE", "SE"])
+    kv = dict(ref=fa, profile=os.path.join(cases.TESTDATA, cases.PROFILES[prof]), name="fz", output=os.path.join(wd, "out"),
+              layout=layout, threads=1, verbose=0, coverage=rng.choice([1, 2, 3, 5, 8]),
+              insertSize=rng.choice([200, 250, 350, 500]), ploidy=rng.choice([2, 2, 2, 1, 3]))
+    big = max(contigs, key=lambda c: c[1])
+    if rng.random() < 0.5 and big[1] >= 90000:
+        rows = cases._variations("fz", big[0][3:], big[1] / 63025520.0)
+        cases._write(os.path.join(wd, "variations.txt"), rows)
+        kv["variation"] = os.path.join(wd, "variations.txt")
+    if rng.random() < 0.5:
+        rows = []
+        for name, length in contigs:
+            if length >= 4000:
+                rows += cases._snps(name[3:], length, rng.choice([300, 1500, 4000]), rng.randrange(1, 99))
+        if rows:
+            cases._write(os.path.join(wd, "snp.txt"), rows)
+            kv["snp"] = os.path.join(wd, "snp.txt")
+    cfg = os.path.join(wd, "config.txt")
+    cases._config(cfg, **kv)
+    return cfg
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("case_seed", list(range(101, 149)))
+def test_random_configuration(case_seed, oracle_lib, tmp_path):
+    rng = random.Random(case_seed)
+    cfg = _make(rng, str(tmp_path))
+    seed = rng.getrandbits(63)
+    odir, gdir = str(tmp_path / "o"), str(tmp_path / "g")
+    rc = oracle_lib.orc_simulate(cfg.encode(), 1, seed >> 32, seed & 0xFFFFFFFF, odir.encode(), 4)
+    r = subprocess.run([SIMU, cfg, "--seed", str(seed), "--out", gdir, "--quiet"], capture_output=True, text=True, timeout=120)
+    if rc != 0:   # whatever the oracle refuses (e.g. a zero-weight genome) the GPU path must refuse too
+        assert r.returncode != 0, (oracle_lib.orc_last_error().decode(), r.stderr[-500:])
+        return
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(os.listdir(odir))
+    assert files == sorted(os.listdir(gdir)) and files
+    for f in files:
+        a, b = open(os.path.join(odir, f), "rb").read(), open(os.path.join(gdir, f), "rb").read()
+        assert a == b, (case_seed, f, len(a), len(b), open(cfg).read())
