@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMU = os.path.join(ROOT, "simuscop_amd", "lib", "simuReads")
 
 
-def _make(rng, wd):
+def _make(rng, wd, extended=False):
     fa = os.path.join(wd, "ref.fa")
     n_contigs = rng.choice([1, 1, 2, 3, 5])
     contigs = [("chr%d" % (i + 1), rng.choice([900, 4000, 30000, 90000, 250000, 1200000])) for i in range(n_contigs)]
@@ -39,16 +39,30 @@ def _make(rng, wd):
         if rows:
             cases._write(os.path.join(wd, "snp.txt"), rows)
             kv["snp"] = os.path.join(wd, "snp.txt")
+    if extended:
+        if rng.random() < 0.4 and big[1] >= 90000:   # exome: BED targets on the largest contig
+            cases._write(os.path.join(wd, "targets.bed"), cases._bed(big[0][3:] if rng.random() < 0.5 else big[0], big[1], rng.randrange(1, 99), rng.choice([3, 20, 60])))
+            kv["target"] = os.path.join(wd, "targets.bed")
+        if rng.random() < 0.35:                        # mixture of populations
+            names = ["fz", "p2", "p3"][:rng.choice([2, 3])]
+            kv["name"] = ", ".join(names)
+            rows = []
+            for _ in range(rng.choice([1, 2])):
+                w = [rng.random() + 0.05 for _ in names]
+                rows.append("\t".join("%.3f" % (x / sum(w)) for x in w[:-1]) + "\t%.3f" % (1 - sum(float("%.3f" % (x / sum(w))) for x in w[:-1])))
+            cases._write(os.path.join(wd, "abundance.txt"), rows)
+            kv["abundance"] = os.path.join(wd, "abundance.txt")
+            kv["ploidy"] = 2
     cfg = os.path.join(wd, "config.txt")
     cases._config(cfg, **kv)
     return cfg
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("case_seed", list(range(101, 149)))
+@pytest.mark.parametrize("case_seed", list(range(101, 149)) + list(range(201, 241)))
 def test_random_configuration(case_seed, oracle_lib, tmp_path):
     rng = random.Random(case_seed)
-    cfg = _make(rng, str(tmp_path))
+    cfg = _make(rng, str(tmp_path), extended=case_seed >= 200)
     seed = rng.getrandbits(63)
     odir, gdir = str(tmp_path / "o"), str(tmp_path / "g")
     rc = oracle_lib.orc_simulate(cfg.encode(), 1, seed >> 32, seed & 0xFFFFFFFF, odir.encode(), 4)
