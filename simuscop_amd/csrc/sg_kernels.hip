@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         if (nslow > SLOW_CAP - 64u) flush_slow();
         const uint32_t i = step * 64u + lane;
         const bool ok = i < n_items;
-        const uint32_t ri = (i * inv_TI) >> 20, c = i - ri * TI;  // i / TI, i % TI (exact: i * TI < 2^20)
+        const uint32_t ri = __umul24(i, inv_TI) >> 20, c = i - __umul24(ri, TI);  // i / TI, i % TI (exact: i * TI < 2^20)
         const uint32_t r = perm[ok ? ri : 0u];
         const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
         const bool head = c == 0u;
