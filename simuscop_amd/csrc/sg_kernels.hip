@@ -764,17 +764,20 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
 }
 
 // ------------------------------------------------------------------------------------------------
-// emit, fast variant for the common profile shape: kmer == 3, quality rows of <= 8 symbols, both
-// tables in LDS.  Same mapping and results as emit_kernel, far fewer instructions:
+// emit, straight-line variant for the common profile shape: kmer == 3, tables in LDS (quality rows of
+// <= 8 symbols whole, wider alphabets with the reference == called rows only: DIAG).  Same results as
+// emit_kernel, far fewer instructions:
 //   * the 13 source codes of an item are packed 2 bits each (natural order A0 C1 T2 G3) into one
 //     word, so a k-mer context is ONE bit-field extract; the LDS copy of the substitution table is
 //     permuted at staging time to that digit order (DevProfile::sub_perm), the quality rows to the
 //     natural reference-base order;
 //   * the 8-base block is straight-line and branch-free (the compiler can overlap the LDS reads of
-//     different bases); first-of-read contexts ("XXb", "Xbb") use per-lane extract constants, the
-//     record tail ("\n+\n", '\n') is patched on the packed 8-byte words;
-//   * windows holding a non-ACGT base and reads with >= 2 sequencing indels (both rare) fall back to
-//     the generic item code, out of line.
+//     different bases); first-of-read contexts ("XXb", "Xbb") use per-lane extract constants;
+//   * a group's reads walk the steps as one item stream, 64 items per step, ordered by event class;
+//   * what is per read rather than per item -- header text, the partial last item, "\n+\n" and '\n' --
+//     is stored by a per-read pass once per group (the last item waits in the read's own LDS row);
+//   * windows holding a non-ACGT base and reads with >= 2 sequencing indels (both rare; DIAG: items
+//     with a substitution) go to a global queue for emit_slow_kernel.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..3) -> 8 bits
   return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
@@ -913,7 +916,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   qw[0] += 0x01010101u * (uint32_t)P.min_qual;
   qw[1] += 0x01010101u * (uint32_t)P.min_qual;
   // A whole item is two 8-byte stores.  The read's last, partial item (np % 8 bases) is parked in the
-  // read's LDS tail row instead: the per-read pass after the step loop merges it with the record
+  // read's own LDS row instead: the per-read pass after the step loop merges it with the record
   // separators, so the byte-granular stores run once per read group rather than in every step.
   if (active) {
     if (i0 + 8u <= np) {
