@@ -205,6 +205,20 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
  * (lib/seqwriter/SeqWriter.cpp:41-54) has no such mode: additive.                                   */
 int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2);
 int sg_fetch_compressed(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, void* host_dst);
+/* ---- detached outputs: drain one batch while the next is sampled ------------------------------------- */
+/* After sg_result (and sg_compress, if wanted) the FASTQ text -- and its BGZF form -- can be taken out of
+ * the context: the handle owns the device buffers and a copy stream of its own, so sg_outputs_fetch may
+ * run on another host thread while the context plans and samples the next batch into fresh buffers
+ * (the reference's workers flush their 50 MB buffers through one mutex instead, Segment.cpp:834-846,
+ * SeqWriter.cpp:49-54).  sg_release_outputs hands the buffers back to the context for reuse; it and
+ * sg_detach_outputs are context calls (one thread at a time), sg_outputs_* are not.                  */
+typedef struct sg_outputs sg_outputs;
+int sg_detach_outputs(sg_ctx* ctx, sg_outputs** out);
+int sg_outputs_sizes(const sg_outputs* o, uint64_t text_bytes[2], uint64_t gz_bytes[2]);
+int sg_outputs_fetch(sg_outputs* o, int mate, int compressed, uint64_t offset, uint64_t bytes, void* host_dst);
+const char* sg_outputs_last_error(const sg_outputs* o);
+int sg_release_outputs(sg_ctx* ctx, sg_outputs* o);
+
 /* the 28-byte empty BGZF block that ends a file */
 int sg_bgzf_eof(uint8_t out[28]);
 /* Host-only view of the code construction, for tests: from a byte histogram, the literal / end-of-block

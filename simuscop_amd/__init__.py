@@ -23,7 +23,8 @@ ENGINE_SYMBOLS = [
     "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
     "sg_upload_haplotypes", "sg_reference_begin", "sg_reference_chunk", "sg_sync", "sg_reference_scan",
     "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_compress", "sg_fetch_compressed",
-    "sg_bgzf_eof", "sg_deflate_plan", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
+    "sg_bgzf_eof", "sg_deflate_plan", "sg_detach_outputs", "sg_outputs_sizes", "sg_outputs_fetch",
+    "sg_outputs_last_error", "sg_release_outputs", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_host_free",
 ]
@@ -121,6 +122,12 @@ def load_engine():
     lib.sg_bgzf_eof.argtypes = [C.c_char_p]
     lib.sg_deflate_plan.argtypes = [C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
     lib.sg_deflate_plan.restype = C.c_uint32
+    lib.sg_detach_outputs.argtypes = [vp, C.POINTER(vp)]
+    lib.sg_outputs_sizes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.sg_outputs_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p]
+    lib.sg_outputs_last_error.argtypes = [vp]
+    lib.sg_outputs_last_error.restype = C.c_char_p
+    lib.sg_release_outputs.argtypes = [vp, vp]
     lib.sg_plan.argtypes = [vp, C.POINTER(SgBatch)]
     lib.sg_sample.argtypes = [vp]
     lib.sg_result.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -91,6 +91,7 @@ struct Driver {
   std::vector<int32_t> gcv;
 
   ~Driver() {
+    if (pending.active && pending.th.joinable()) pending.th.join();
     for (void* b : pinned)
       if (b && eng.ctx) sg_host_free(eng.ctx, b);
   }
@@ -363,16 +364,53 @@ struct Driver {
     st.fragments += nf;
     st.reads += paired ? 2 * nf : nf;
     st.fastq_bytes += n1 + n2;
-    if (opt.gzip && (opt.write_files || opt.fetch)) {
+    if (!(opt.write_files || opt.fetch)) return;
+    bool compressed = false;
+    if (opt.gzip) {
       auto tc = Clock::now();
       uint64_t g1 = 0, g2 = 0;
       eng.check(sg_compress(eng.ctx, &g1, &g2), "sg_compress");
       st.t_compress += since(tc);
       st.gz_bytes += g1 + g2;
-      drain(g1, g2, sink, true);
-    } else if (opt.write_files || opt.fetch) {
-      drain(n1, n2, sink, false);
+      compressed = true;
     }
+    // The text leaves the context as a detached output set and is drained by a worker thread (D2H on the
+    // set's own stream + the file writers) while this thread plans and samples the next batch.  One
+    // drain at a time: the pinned buffers, the files and their order belong to it.
+    drain_wait();
+    for (int i = 0; i < (paired ? 4 : 2); i++)   // context calls stay on this thread
+      if (!pinned[i]) eng.check(sg_host_alloc(eng.ctx, kChunk, &pinned[i]), "sg_host_alloc");
+    sg_outputs* h = nullptr;
+    eng.check(sg_detach_outputs(eng.ctx, &h), "sg_detach_outputs");
+    pending.handle = h;
+    pending.active = true;
+    pending.err.clear();
+    pending.t_fetch = pending.t_write = 0;
+    FILE* f1 = opt.write_files ? sink.f1 : nullptr;
+    FILE* f2 = opt.write_files ? sink.f2 : nullptr;
+    pending.th = std::thread([this, h, f1, f2, compressed]() {
+      try { drain(h, f1, f2, compressed); }
+      catch (const std::exception& e) { pending.err = e.what(); }
+    });
+  }
+
+  struct PendingDrain {
+    sg_outputs* handle = nullptr;
+    std::thread th;
+    bool active = false;
+    std::string err;
+    double t_fetch = 0, t_write = 0;
+  } pending;
+  // joins the drain in flight (if any), books its times, returns its buffers to the engine
+  void drain_wait() {
+    if (!pending.active) return;
+    pending.th.join();
+    pending.active = false;
+    st.t_fetch += pending.t_fetch;
+    st.t_write += pending.t_write;
+    eng.check(sg_release_outputs(eng.ctx, pending.handle), "sg_release_outputs");
+    pending.handle = nullptr;
+    if (!pending.err.empty()) throw Error(pending.err, -1);
   }
 
   // FASTQ sink (the reference's SeqWriter::write, lib/seqwriter/SeqWriter.cpp:41-54): D2H in pinned
@@ -382,10 +420,11 @@ struct Driver {
   // their own files, so pair order is kept.
   static constexpr size_t kChunk = 64u << 20;
   void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};
-  void drain(uint64_t n1, uint64_t n2, Sink& sink, bool compressed) {
+  void drain(sg_outputs* h, FILE* f1, FILE* f2, bool compressed) {
     const int mates = cfg.paired() ? 2 : 1;
-    for (int i = 0; i < 2 * mates; i++)
-      if (!pinned[i]) eng.check(sg_host_alloc(eng.ctx, kChunk, &pinned[i]), "sg_host_alloc");
+    uint64_t tb[2], gb[2];
+    sg_outputs_sizes(h, tb, gb);
+    const uint64_t n1 = compressed ? gb[0] : tb[0], n2 = compressed ? gb[1] : tb[1];
     struct Writer {
       std::mutex mu;
       std::condition_variable cv;
@@ -432,19 +471,19 @@ struct Driver {
         const size_t n = (size_t)std::min<uint64_t>(kChunk, total[m] - off);
         void* buf = pinned[2 * m + cur[m]];
         // this buffer's previous chunk was posted two rounds ago; the copy overlaps both writers' fwrite
-        rc = compressed ? sg_fetch_compressed(eng.ctx, m, off, n, buf) : sg_fetch_range(eng.ctx, m, off, n, (char*)buf);
+        rc = sg_outputs_fetch(h, m, compressed ? 1 : 0, off, n, buf);
         w[m].wait_idle();  // the mate's other buffer is free again
-        if (rc == SG_OK) w[m].post(opt.write_files ? (m ? sink.f2 : sink.f1) : nullptr, (const char*)buf, n);
+        if (rc == SG_OK) w[m].post(m ? f2 : f1, (const char*)buf, n);
         cur[m] ^= 1;
       }
     }
     double t_write = 0;
     bool failed = false;
     for (int m = 0; m < mates; m++) { w[m].finish(); t_write = std::max(t_write, w[m].t_write); failed |= w[m].failed; }
-    eng.check(rc, compressed ? "sg_fetch_compressed" : "sg_fetch_range");
+    if (rc != SG_OK) throw Error(std::string("GPU engine error in sg_outputs_fetch: ") + sg_outputs_last_error(h));
     const double wall = since(t0);
-    st.t_write += t_write;
-    st.t_fetch += wall > t_write ? wall - t_write : 0;  // fetch time not hidden behind the writers
+    pending.t_write = t_write;
+    pending.t_fetch = wall > t_write ? wall - t_write : 0;  // fetch time not hidden behind the writers
     if (failed) throw Error("Error: short write to fastq file", -1);
   }
 
@@ -507,6 +546,7 @@ struct Driver {
           snprintf(buf, sizeof buf, i == 0 ? "%s_%.3f" : "+%s_%.3f", popus[i].c_str(), props[i]);
           stem += buf;
         }
+        drain_wait();  // the previous mixture's last batch still writes into the files about to be closed
         if (opt.write_files) sink.open(out_dir, stem, paired, suffix, opt.gzip != 0);
         for (size_t i = 0; i < popus.size(); i++) {
           const long popu_reads = (long)(reads * props[i] * acn[popus[i]] / w_acn);  // long*float is a float product (Genome.cpp:935)
@@ -515,6 +555,7 @@ struct Driver {
         }
       }
     }
+    drain_wait();
     sink.close();
     log("\nReads generation done!\n");
     st.t_total = since(t_all);

@@ -79,6 +79,14 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+struct sg_outputs {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf text[2], gz[2];
+  uint64_t text_bytes[2] = {0, 0}, gz_bytes[2] = {0, 0};
+  std::string err;
+};
+
 struct sg_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -93,6 +101,7 @@ struct sg_ctx {
       recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work, gz1, gz2, gz_work;
   uint64_t gz_bytes[2] = {0, 0};
   bool gz_valid = false;
+  std::vector<sg_outputs*> spare;  // released output sets, reused by the next pass
   uint64_t ref_raw_bytes = 0;
   std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
@@ -162,6 +171,11 @@ void sg_destroy(sg_ctx* ctx) {
                     &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq,
                     &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work, &ctx->gz1, &ctx->gz2, &ctx->gz_work})
     b->release();
+  for (sg_outputs* o : ctx->spare) {
+    for (int m = 0; m < 2; m++) { o->text[m].release(); o->gz[m].release(); }
+    if (o->stream) (void)hipStreamDestroy(o->stream);
+    delete o;
+  }
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -343,6 +357,68 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   }
   ctx->have_profile = true;
   ctx->have_plan = false;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// detached outputs
+// ------------------------------------------------------------------------------------------------
+int sg_detach_outputs(sg_ctx* ctx, sg_outputs** out) {
+  if (!ctx || !out) return SG_ERR_INVALID;
+  if (!ctx->results_valid) return ctx->fail(SG_ERR_INVALID, "sg_detach_outputs: call sg_result first");
+  SG_HIP(hipSetDevice(ctx->device));
+  sg_outputs* o = nullptr;
+  if (!ctx->spare.empty()) { o = ctx->spare.back(); ctx->spare.pop_back(); }
+  if (!o) {
+    o = new sg_outputs();
+    o->device = ctx->device;
+    hipError_t e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete o; return ctx->hipfail(e, "hipStreamCreate(outputs)"); }
+  }
+  // whatever the spare still holds goes back to the context (it is empty or smaller than what was just used)
+  std::swap(ctx->out1, o->text[0]); std::swap(ctx->out2, o->text[1]);
+  std::swap(ctx->gz1, o->gz[0]); std::swap(ctx->gz2, o->gz[1]);
+  o->text_bytes[0] = ctx->host_totals[0];
+  o->text_bytes[1] = ctx->B.paired ? ctx->host_totals[1] : 0;
+  o->gz_bytes[0] = ctx->gz_valid ? ctx->gz_bytes[0] : 0;
+  o->gz_bytes[1] = ctx->gz_valid ? ctx->gz_bytes[1] : 0;
+  ctx->results_valid = false;
+  ctx->sampled = false;
+  ctx->gz_valid = false;
+  *out = o;
+  return SG_OK;
+}
+
+int sg_outputs_sizes(const sg_outputs* o, uint64_t text_bytes[2], uint64_t gz_bytes[2]) {
+  if (!o) return SG_ERR_INVALID;
+  for (int m = 0; m < 2; m++) {
+    if (text_bytes) text_bytes[m] = o->text_bytes[m];
+    if (gz_bytes) gz_bytes[m] = o->gz_bytes[m];
+  }
+  return SG_OK;
+}
+
+const char* sg_outputs_last_error(const sg_outputs* o) { return o ? o->err.c_str() : ""; }
+
+int sg_outputs_fetch(sg_outputs* o, int mate, int compressed, uint64_t offset, uint64_t bytes, void* host_dst) {
+  if (!o || mate < 0 || mate > 1 || (bytes && !host_dst)) return SG_ERR_INVALID;
+  const uint64_t have = compressed ? o->gz_bytes[mate] : o->text_bytes[mate];
+  if (offset + bytes > have) { o->err = "sg_outputs_fetch: range past the end of the data"; return SG_ERR_INVALID; }
+  if (!bytes) return SG_OK;
+  hipError_t e = hipSetDevice(o->device);
+  const uint8_t* src = (compressed ? o->gz[mate] : o->text[mate]).as<uint8_t>() + offset;
+  if (e == hipSuccess) e = hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, o->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
+  if (e != hipSuccess) { o->err = std::string("sg_outputs_fetch: ") + hipGetErrorString(e); return SG_ERR_HIP; }
+  return SG_OK;
+}
+
+int sg_release_outputs(sg_ctx* ctx, sg_outputs* o) {
+  if (!ctx || !o) return SG_ERR_INVALID;
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_HIP(hipStreamSynchronize(o->stream));
+  o->text_bytes[0] = o->text_bytes[1] = o->gz_bytes[0] = o->gz_bytes[1] = 0;
+  ctx->spare.push_back(o);
   return SG_OK;
 }
 
@@ -776,6 +852,12 @@ static int run_pass(sg_ctx* ctx) {
   SG_HIP(hipMemcpyAsync(ctx->host_totals, B.totals, 4 * 8, hipMemcpyDeviceToHost, s));
   SG_HIP(hipStreamSynchronize(s));
   if (ctx->host_totals[3] & 1) return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
+  if (!ctx->out1.p && !ctx->out2.p && !ctx->gz1.p && !ctx->gz2.p && !ctx->spare.empty()) {
+    // a released output set (sg_release_outputs): its buffers become this pass's
+    sg_outputs* o = ctx->spare.back();
+    std::swap(ctx->out1, o->text[0]); std::swap(ctx->out2, o->text[1]);
+    std::swap(ctx->gz1, o->gz[0]); std::swap(ctx->gz2, o->gz[1]);
+  }
   SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
   if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
   B.out[0] = ctx->out1.as<uint8_t>();
