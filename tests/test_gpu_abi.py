@@ -167,3 +167,45 @@ def test_shipped_profiles_get_the_straight_line_emit_kernel(prof, want, tmp_path
         assert sess.eng.sg_emit_variant(sess.ctx) == want
     finally:
         sess.close()
+
+
+def test_detached_outputs_survive_the_next_pass(tmp_path):
+    """sg_detach_outputs: the text of pass 1 stays fetchable (own buffers, own stream) while pass 2 runs and
+    overwrites nothing of it; released sets are reused; the context refuses fetches after a detach."""
+    cfg = cases.build_case("wgs_pe_xten", str(tmp_path))
+    sess = simuscop_amd.Session(cfg, device=0, write_files=0, quiet=1, seed=21)
+    eng = sess.eng
+    try:
+        sess.weighted_length()
+        sess.set_reads(sess.planned_reads)
+        assert sess.prepare_batch(0)
+        sess.sample()
+        b1, b2, nf = sess.result()
+        t1, t2 = sess.fetch(b1, b2)
+        g1, g2 = sess.compress()
+        z1 = sess.fetch_compressed(0, g1)
+        h = C.c_void_p()
+        assert eng.sg_detach_outputs(sess.ctx, C.byref(h)) == 0
+        buf = C.create_string_buffer(16)
+        assert eng.sg_fetch_range(sess.ctx, 0, 0, 16, buf) != 0       # nothing left in the context
+        sess.set_seed(22)
+        sess.sample()                                                  # pass 2 into fresh buffers
+        c1, c2, _ = sess.result()
+        u1, u2 = sess.fetch(c1, c2)
+        assert u1 != t1
+        tb, gb = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        assert eng.sg_outputs_sizes(h, tb, gb) == 0 and (tb[0], tb[1], gb[0]) == (b1, b2, g1)
+        for mate, want in ((0, t1), (1, t2)):
+            got = C.create_string_buffer(len(want))
+            assert eng.sg_outputs_fetch(h, mate, 0, 0, len(want), got) == 0
+            assert got.raw == want
+        got = C.create_string_buffer(g1)
+        assert eng.sg_outputs_fetch(h, 0, 1, 0, g1, got) == 0 and got.raw == z1
+        assert eng.sg_outputs_fetch(h, 0, 0, b1 - 3, 8, got) != 0    # range check
+        assert eng.sg_release_outputs(sess.ctx, h) == 0
+        sess.set_seed(21)
+        sess.sample()                                                  # reuses the released set
+        d1, d2, _ = sess.result()
+        assert sess.fetch(d1, d2) == (t1, t2)
+    finally:
+        sess.close()
