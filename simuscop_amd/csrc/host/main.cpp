@@ -1,12 +1,20 @@
 // host/main.cpp -- `simuReads <configuration file>` (src/simuReads.cpp:24-97), GPU-backed.
 // Same positional argument, usage text and exit codes; optional flags are additive:
-//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes  --gzip
+//   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes  --gzip  --gpus N
+#include <dirent.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <fstream>
 #include <iostream>
+#include <map>
 #include <string>
+#include <vector>
 
 #include "simulate.h"
 
@@ -14,6 +22,83 @@ static void usage(const char* app) {
   std::cerr << "\nVersion: 1.0 (MI355X engine)\n\n"
             << "Usage: " << app << " <configuration file> [--seed N] [--device D] [--out DIR] [--no-write] [--quiet]\n\n"
             << "Example:\n    " << app << " /path/to/config.txt\n\n";
+}
+
+// --gpus N: one child process per GPU (exec'd before anything here touches the GPU), child r samples
+// the r-th run of segments of every (population, chromosome) batch (--rank r --world N --device r) into
+// <file>.part<r>; the parts of a file are then concatenated in rank order.  Every draw is addressed inside
+// the whole batch, so the reads are those of the one-GPU run (record order aside, which the reference
+// does not define either).  No collective is needed: each child derives the read counts from the whole
+// genome itself.  `python -m simuscop_amd.run` is the torch.distributed (RCCL) front end of the same thing.
+static int run_on_gpus(int gpus, int base_device, const std::vector<std::string>& args, const std::string& self,
+                       const std::string& config, const std::string& out_override, bool merge) {
+  std::vector<pid_t> kids;
+  for (int r = 0; r < gpus; r++) {
+    pid_t pid = fork();
+    if (pid < 0) { std::cerr << "Error: fork failed" << std::endl; return 1; }
+    if (pid == 0) {
+      std::vector<std::string> a = args;
+      // SIMUSCOP_SAME_DEVICE: rehearsal of the sharding on a one-GPU box (all children on the base device)
+      const int dev = getenv("SIMUSCOP_SAME_DEVICE") ? base_device : base_device + r;
+      a.insert(a.end(), {"--rank", std::to_string(r), "--world", std::to_string(gpus), "--device", std::to_string(dev)});
+      if (r > 0) a.push_back("--quiet");
+      std::vector<char*> cv;
+      cv.push_back(const_cast<char*>(self.c_str()));
+      for (std::string& x : a) cv.push_back(const_cast<char*>(x.c_str()));
+      cv.push_back(nullptr);
+      execv(self.c_str(), cv.data());
+      _exit(127);
+    }
+    kids.push_back(pid);
+  }
+  int rc = 0;
+  for (pid_t pid : kids) {
+    int st = 0;
+    waitpid(pid, &st, 0);
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+    if (code != 0 && rc == 0) rc = code;
+  }
+  if (rc != 0 || !merge) return rc;
+  std::string dir = out_override;
+  if (dir.empty()) {
+    std::ifstream f(config);
+    std::string line;
+    while (std::getline(f, line)) {
+      size_t eq = line.find('=');
+      if (eq == std::string::npos) continue;
+      std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+      auto trim = [](std::string& t) { t.erase(0, t.find_first_not_of(" \t\r")); t.erase(t.find_last_not_of(" \t\r") + 1); };
+      trim(k); trim(v);
+      if (k == "output") dir = v;
+    }
+  }
+  std::map<std::string, std::vector<std::pair<int, std::string>>> parts;
+  if (DIR* d = opendir(dir.c_str())) {
+    while (dirent* e = readdir(d)) {
+      const std::string n = e->d_name;
+      const size_t p = n.rfind(".part");
+      if (p == std::string::npos || p + 5 >= n.size()) continue;
+      parts[n.substr(0, p)].emplace_back(atoi(n.c_str() + p + 5), n);
+    }
+    closedir(d);
+  }
+  std::vector<char> buf(16u << 20);
+  for (auto& kv : parts) {
+    std::sort(kv.second.begin(), kv.second.end());
+    FILE* dst = fopen((dir + "/" + kv.first).c_str(), "wb");
+    if (!dst) { std::cerr << "Error: can not open fastq file to save results:\n" << dir + "/" + kv.first << std::endl; return -1; }
+    for (auto& pr : kv.second) {
+      const std::string path = dir + "/" + pr.second;
+      if (FILE* src = fopen(path.c_str(), "rb")) {
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), src)) > 0) fwrite(buf.data(), 1, got, dst);
+        fclose(src);
+        unlink(path.c_str());
+      }
+    }
+    fclose(dst);
+  }
+  return 0;
 }
 
 int main(int argc, char* argv[]) {
@@ -26,6 +111,8 @@ int main(int argc, char* argv[]) {
   simu_default_options(&opt);
   std::string config, out;
   bool stats = false;
+  int gpus = 1;
+  std::vector<std::string> pass;  // arguments handed on to --gpus children
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto val = [&]() -> const char* {
@@ -43,12 +130,25 @@ int main(int argc, char* argv[]) {
     else if (a == "--stats") stats = true;
     else if (a == "--host-haplotypes") opt.host_haplotypes = 1;
     else if (a == "--gzip") opt.gzip = 1;
+    else if (a == "--gpus") { gpus = atoi(val()); continue; }
     else if (config.empty()) config = a;
     else {
       std::cerr << "Error: too many input arguments!" << std::endl;
       usage(argv[0]);
       return 1;
     }
+  }
+  if (gpus > 1) {
+    for (int i = 1; i < argc; i++) {
+      const std::string a = argv[i];
+      if (a == "--gpus" || a == "--device" || a == "--rank" || a == "--world") { i++; continue; }
+      pass.push_back(a);
+    }
+    char self[4096];
+    const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    if (n <= 0) { std::cerr << "Error: cannot locate the executable for --gpus" << std::endl; return 1; }
+    self[n] = 0;
+    return run_on_gpus(gpus, opt.device >= 0 ? opt.device : 0, pass, self, config, out, opt.write_files != 0);
   }
   time_t start_t = time(NULL);
   simu_stats st;

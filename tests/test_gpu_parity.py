@@ -116,3 +116,25 @@ def test_launcher_two_ranks_merge(tmp_path):
         whole = _records(open(os.path.join(one, f), "rb").read())
         merged = _records(open(os.path.join(out_dir, f), "rb").read())
         assert sorted(whole) == sorted(merged), f
+
+
+def test_cli_gpus_option_equals_one_gpu(tmp_path):
+    """simuReads --gpus 3 (child process per GPU, here all on device 0): the merged files hold exactly the
+    records of the one-GPU run, also as BGZF."""
+    cfg = cases.build_case("wgs_pe_variants", str(tmp_path))
+    one = str(tmp_path / "one")
+    _run_gpu(cfg, one)
+    env = dict(os.environ, SIMUSCOP_SAME_DEVICE="1")
+    for tag, extra in (("three", []), ("three_gz", ["--gzip"])):
+        d = str(tmp_path / tag)
+        r = subprocess.run([SIMU, cfg, "--seed", str(SEED), "--out", d, "--quiet", "--gpus", "3", *extra],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for f in _files(one):
+            name = f + (".gz" if extra else "")
+            assert sorted(os.listdir(d)) == sorted(x + (".gz" if extra else "") for x in _files(one))
+            blob = open(os.path.join(d, name), "rb").read()
+            if extra:
+                import gzip
+                blob = gzip.decompress(blob)
+            assert sorted(_records(blob)) == sorted(_records(open(os.path.join(one, f), "rb").read())), (tag, f)
