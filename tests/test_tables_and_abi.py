@@ -106,3 +106,14 @@ def test_config_errors_match_reference_messages(tmp_path):
     cfg.write_text("ref = x.fa\nprofile = p\nname = a, b\noutput = o\ncoverage = 1\n")
     with pytest.raises(simuscop_amd.SimuError, match="abundance file not specified"):
         simuscop_amd.run_config(str(cfg), quiet=1)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/simuscop_amd.h is the drop-in boundary: it must compile as C99 (no C++ or torch types) and as
+    C++11 (the reference's language level, CMakeLists.txt:4)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "simuscop_amd.h"\nint main(void) { return sg_create(0, 0, 0) == SG_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
