@@ -251,19 +251,33 @@ struct Driver {
   }
 
   // one (population, chromosome): Genome.cpp:870-887
-  // Builds the sampling plan of one (population, chromosome) and hands it to the engine (chains
-  // uploaded, sg_plan done).  Returns false when this process has nothing to sample in the batch.
-  bool prepare_batch(const std::string& popu, const std::string& chr) {
-    ChromPlan& plan = genome.plans[popu][chr];
-    const uint32_t bid = batch_id++;
-    if (bid > 0xFFFF) throw Error("ERROR: more than 65535 (population, chromosome) batches");
-    st.batches++;
-    const bool paired = cfg.paired();
-    auto t0 = Clock::now();
-    // windows of the segments the reference would process (Segment.cpp:675), with fragRCs
-    // (Segment::setReadCount, Segment.cpp:462-476)
-    struct Active { size_t seg; uint32_t w_first; uint64_t slots; };
+  // The sampling plan of one (population, chromosome): windows of the segments the reference would process
+  // (Segment.cpp:675) with their fragRCs (Segment::setReadCount, Segment.cpp:462-476), numbered inside the
+  // whole batch.  Any contiguous run of its segments can then be handed to the engine on its own
+  // (plan_range): the run of a multi-GPU shard, or a memory-bounded piece of it -- the draws are addressed
+  // by the batch-wide numbers, so the pieces' texts concatenate to the text of the whole.
+  struct Active { size_t seg; uint32_t w_first; uint64_t slots; };
+  struct BatchPlan {
+    std::string popu, chr, prefix;
+    uint32_t bid = 0;
+    bool paired = false;
     std::vector<Active> act;
+    uint64_t slots = 0;
+    size_t a0 = 0, a1 = 0;  // this process's run of active segments (multi-GPU shard)
+  } cur;
+
+  // false: nothing to sample in the batch (for this process)
+  bool build_batch(const std::string& popu, const std::string& chr) {
+    ChromPlan& plan = genome.plans[popu][chr];
+    cur = BatchPlan();
+    cur.popu = popu; cur.chr = chr;
+    cur.bid = batch_id++;
+    if (cur.bid > 0xFFFF) throw Error("ERROR: more than 65535 (population, chromosome) batches");
+    st.batches++;
+    const bool paired = cur.paired = cfg.paired();
+    cur.prefix = "@" + popu + "#" + chr + "#";
+    auto t0 = Clock::now();
+    std::vector<Active>& act = cur.act;
     wins.clear(); seg_size.clear(); seg_first.clear();
     uint64_t slot = 0;
     for (size_t k = 0; k < plan.segs.size(); k++) {
@@ -292,25 +306,32 @@ struct Driver {
     }
     seg_first.push_back((uint32_t)wins.size());
     if (slot > 0xFFFFFFF0ull) throw Error("ERROR: more than 2^32 fragments on chromosome " + chr);
+    cur.slots = slot;
     st.windows += wins.size();
     st.segments += act.size();
     st.t_plan += since(t0);
     if (wins.empty()) return false;
 
     // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
-    size_t a0 = 0, a1 = act.size();
+    cur.a0 = 0; cur.a1 = act.size();
     if (opt.shard_world > 1) {
       const uint64_t per = (slot + opt.shard_world - 1) / opt.shard_world;
       uint64_t acc = 0;
-      a0 = a1 = act.size();
+      cur.a0 = cur.a1 = act.size();
       bool started = false;
       for (size_t i = 0; i < act.size(); i++) {
         const int owner = per ? (int)std::min<uint64_t>(acc / per, (uint64_t)opt.shard_world - 1) : 0;
-        if (owner == opt.shard_rank) { if (!started) { a0 = i; started = true; } a1 = i + 1; }
+        if (owner == opt.shard_rank) { if (!started) { cur.a0 = i; started = true; } cur.a1 = i + 1; }
         acc += act[i].slots;
       }
       if (!started) return false;
     }
+    return true;
+  }
+
+  // chains on the device, sg_plan for the active segments [a0, a1) of the current batch
+  void plan_range(size_t a0, size_t a1) {
+    const std::vector<Active>& act = cur.act;
     const uint32_t w_lo = act[a0].w_first;
     const uint32_t w_hi = a1 < act.size() ? act[a1].w_first : (uint32_t)wins.size();
     const uint32_t slot_lo = wins[w_lo].slot_base;
@@ -320,14 +341,13 @@ struct Driver {
     sh_first.push_back(w_hi - w_lo);
     for (sg_window& w : shard) { w.seg -= (uint32_t)a0; w.slot_base -= slot_lo; }
 
-    t0 = Clock::now();
-    upload(popu, chr);
-    const std::string prefix = "@" + popu + "#" + chr + "#";
+    auto t0 = Clock::now();
+    upload(cur.popu, cur.chr);
     sg_batch b;
     std::memset(&b, 0, sizeof b);
-    b.batch_id = bid;
-    b.paired = paired ? 1 : 0;
-    b.name_prefix = prefix.c_str();
+    b.batch_id = cur.bid;
+    b.paired = cur.paired ? 1 : 0;
+    b.name_prefix = cur.prefix.c_str();
     b.windows = shard.data();
     b.n_windows = shard.size();
     b.seg_size = sh_size.data();
@@ -339,12 +359,36 @@ struct Driver {
     eng.check(sg_plan(eng.ctx, &b), "sg_plan");
     st.t_plan_api += since(t_pl);
     st.t_sample += since(t0);
+  }
+
+  // the whole shard as one engine batch (step-by-step sessions: bench.py keeps it resident)
+  bool prepare_batch(const std::string& popu, const std::string& chr) {
+    if (!build_batch(popu, chr)) return false;
+    plan_range(cur.a0, cur.a1);
     return true;
   }
 
+  // Pieces of at most kPieceSlots planned fragments (whole segments; a segment is <= 1 Mbp per copy): the
+  // work buffers of a pass are ~0.5 KB per fragment and its text ~0.7 KB, so a 250 Mbp chromosome at 30x
+  // is a handful of pieces of ~10 GB, and a 1000x run still fits the card.  Each piece drains while the
+  // next one is sampled.
+  static constexpr uint64_t kPieceSlots = 12u << 20;
   void run_batch(const std::string& popu, const std::string& chr, Sink& sink) {
-    if (!prepare_batch(popu, chr)) return;
-    const bool paired = cfg.paired();
+    if (!build_batch(popu, chr)) return;
+    uint64_t piece_slots = kPieceSlots;
+    if (const char* e = getenv("SIMU_PIECE_SLOTS")) piece_slots = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    for (size_t c0 = cur.a0; c0 < cur.a1;) {
+      size_t c1 = c0;
+      uint64_t acc = 0;
+      while (c1 < cur.a1 && (c1 == c0 || acc + cur.act[c1].slots <= piece_slots)) acc += cur.act[c1++].slots;
+      run_piece(c0, c1, sink);
+      c0 = c1;
+    }
+  }
+
+  void run_piece(size_t c0, size_t c1, Sink& sink) {
+    plan_range(c0, c1);
+    const bool paired = cur.paired;
     auto t0 = Clock::now();
     uint64_t n1 = 0, n2 = 0, nf = 0;
     const int reps = opt.repeat_sample > 1 ? opt.repeat_sample : 1;
