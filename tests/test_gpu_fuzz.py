@@ -75,7 +75,17 @@ def test_random_configuration(case_seed, oracle_lib, tmp_path):
     seed = rng.getrandbits(63)
     odir, gdir = str(tmp_path / "o"), str(tmp_path / "g")
     rc = oracle_lib.orc_simulate(cfg.encode(), 1, seed >> 32, seed & 0xFFFFFFFF, odir.encode(), 4)
-    r = subprocess.run([SIMU, cfg, "--seed", str(seed), "--out", gdir, "--quiet"], capture_output=True, text=True, timeout=120)
+    extra, env = [], dict(os.environ)
+    if case_seed >= 200:   # engine / host variants that must not change a byte
+        if rng.random() < 0.3:
+            extra.append("--host-haplotypes")
+        if rng.random() < 0.3:
+            env["SIMU_PIECE_SLOTS"] = str(rng.choice([1, 700, 5000]))
+        if rng.random() < 0.2:
+            env["SG_EMIT_MAP"] = "fixed"
+        if rng.random() < 0.2:
+            env["SG_SLOWQ_CAP"] = str(rng.choice([1, 64, 4096]))
+    r = subprocess.run([SIMU, cfg, "--seed", str(seed), "--out", gdir, "--quiet", *extra], capture_output=True, text=True, timeout=120, env=env)
     if rc != 0:   # whatever the oracle refuses (e.g. a zero-weight genome) the GPU path must refuse too
         assert r.returncode != 0, (oracle_lib.orc_last_error().decode(), r.stderr[-500:])
         return
@@ -84,4 +94,4 @@ def test_random_configuration(case_seed, oracle_lib, tmp_path):
     assert files == sorted(os.listdir(gdir)) and files
     for f in files:
         a, b = open(os.path.join(odir, f), "rb").read(), open(os.path.join(gdir, f), "rb").read()
-        assert a == b, (case_seed, f, len(a), len(b), open(cfg).read())
+        assert a == b, (case_seed, f, len(a), len(b), extra, {k: env[k] for k in env if k.startswith(("SG_", "SIMU_"))}, open(cfg).read())
