@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 #define PLAN_S 8
 
 __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch& B, const sg_window& win, uint64_t w,
-                                             uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r) {
+                                             uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r, const uint32_t* isz_row) {
   uint32_t x[4];
   philox4x32_10((uint32_t)w + B.win_offset, attempt, 0, c3, B.k0, B.k1, x);
   // threadPool->randomInteger(spos, epos+1): (long)(start + (end-start)*(x/2^32)) in fp64
@@ -98,7 +98,7 @@ __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch
   const double v = __dadd_rn((double)win.spos, __dmul_rn((double)win.len, frac));
   const uint32_t pos = (uint32_t)(long long)v;
   uint32_t isz;
-  if (B.paired) isz = P.isz_row ? (uint32_t)P.isz_min + row_search(P.isz_row, P.isz_lg, x[1]) : (uint32_t)P.fixed_isz;
+  if (B.paired) isz = isz_row ? (uint32_t)P.isz_min + row_search(isz_row, P.isz_lg, x[1]) : (uint32_t)P.fixed_isz;
   else isz = win.len;
   const uint64_t avail = clen - (win.hap_base + pos);
   const uint32_t flen = avail < (uint64_t)isz ? (uint32_t)avail : isz;
@@ -108,6 +108,14 @@ __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch
 }
 
 __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
+  // the insert-size row (nine dependent probes per fragment) in LDS when it fits
+  __shared__ uint32_t isz_lds[1025];
+  const uint32_t* isz_row = P.isz_row;
+  if (P.isz_row && P.isz_lg <= 10u) {
+    for (uint32_t i = threadIdx.x; i < (1u << P.isz_lg) + 1u; i += blockDim.x) isz_lds[i] = P.isz_row[i];
+    isz_row = isz_lds;
+  }
+  __syncthreads();
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t w = gid / PLAN_S;
   const uint32_t j = (uint32_t)(gid % PLAN_S);
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   if (safe) {
     for (uint32_t k = j; k < planned; k += PLAN_S) {
       PairRec r;
-      plan_attempt(P, B, win, w, k, clen, c3, r);
+      plan_attempt(P, B, win, w, k, clen, c3, r, isz_row);
       r.k = k;
       B.pairs[win.slot_base + k] = r;
     }
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   uint32_t done = 0, fail = 0, attempt = 0;
   while (done < planned) {
     PairRec r;
-    if (!plan_attempt(P, B, win, w, attempt++, clen, c3, r)) {
+    if (!plan_attempt(P, B, win, w, attempt++, clen, c3, r, isz_row)) {
       if (++fail > 1000) break;
       continue;
     }
