@@ -795,7 +795,8 @@ template <bool PAIRED, bool DIAG, bool GUARD>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
                                           const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
-                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1, uint4* tail_row) {
+                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1, uint4* tail_row, int d0, uint32_t n_in,
+                                          uint32_t ew_in, uint32_t tj_in) {
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
@@ -803,12 +804,16 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   // offset, reciprocal and event word then hold the parked last item (see below), so an idle lane must
   // not follow them -- it reads a harmless in-bounds window and has no event.  With the fixed map an
   // idle lane only ever sees rows of reads of its own step, which are still intact when it loads them.
-  const uint32_t np = m1.y & 0xFFFFu, nev = (GUARD && !active) ? 0u : ((m1.y >> 16) & 0x3Fu), hdr = m1.y >> 22;
+  // The caller has reduced the read's sequencing indels to what this item sees: d0 = template index minus
+  // output index at the item's first position (events before it), n_in = events reaching into it (0, 1,
+  // or 2 = too many for the two-window code), ew_in = that event with its OUTPUT position, tj_in = its
+  // template position (the address of its draws).
+  const uint32_t np = m1.y & 0xFFFFu, nev = (GUARD && !active) ? 0u : n_in, hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
   const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
   const bool no_frag = GUARD ? !active : flen == 0u;
-  const uint8_t* src = no_frag ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 : frag + (int)i0 - 5);
+  const uint8_t* src = no_frag ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 - d0 : frag + (int)i0 - 5 + d0);
 
   // 16 encoded bytes -> byte order by position (reverse reads), complement, validity, 2-bit pack
   auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
@@ -829,7 +834,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   // reads with exactly one sequencing indel: past the event the window is shifted by +-len
   if (__ballot(nev == 1u) != 0ull) {
     if (nev == 1u) {
-      const uint32_t ew = m1.w;
+      const uint32_t ew = ew_in;
       const int ej = (int)(ew & 0xFFFFu), elen = (int)((ew >> 16) & 0x7FFFu);
       const bool del = (ew >> 31) != 0;
       const int delta = del ? elen : -elen;
@@ -849,7 +854,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
           const bool ins = p > ej && p <= ej + elen;
           if (__ballot(ins) == 0ull) continue;
           if (ins) {
-            const uint32_t prof = __umulhi(aux_draw(B, slot, (uint32_t)ej, (uint32_t)(p - ej), m), 3u);
+            const uint32_t prof = __umulhi(aux_draw(B, slot, tj_in, (uint32_t)(p - ej), m), 3u);
             const uint32_t nat = (P.inv_remap_packed >> (2u * prof)) & 3u;
             cw = (cw & ~(3u << (2 * q))) | (nat << (2 * q));
           }
@@ -1053,38 +1058,28 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       nslow = 0;
       wave_lds_sync();
     };
-    // Order of the group's reads through the step loop: reads without a sequencing indel first, then
-    // the reads with one (so that the two-window code runs in ~4 of 21 steps instead of whenever one
-    // of a step's reads has an event, 42 % of the steps at XTen rates).  Reads with >= 2 events never
-    // enter the loop: all their items are queued here.
+    // Order of the group's reads through the step loop: reads without a sequencing indel first, then the
+    // reads with one, then the reads with several (so that the two-window code and the event-list walk run
+    // in the few steps that need them instead of whenever one of a step's reads has an event, 42 % of the
+    // steps at XTen rates).
     const uint32_t nev_l = (my1.y >> 16) & 0x3Fu;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long in_group = G >= 64u ? ~0ull : ((1ull << G) - 1ull);
     const unsigned long long m_multi = __ballot(items > 0u && nev_l >= 2u);
     const unsigned long long m_one = __ballot(items > 0u && nev_l == 1u);
     const unsigned long long m_rest = in_group & ~(m_multi | m_one);
-    const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_fast = n_rest + (uint32_t)__popcll(m_one);
+    const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_one = (uint32_t)__popcll(m_one);
+    const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // all of them walk the steps
     if (lane < G) {
       uint32_t pos;
       if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
       else if ((m_one >> lane) & 1ull) pos = n_rest + (uint32_t)__popcll(m_one & lt);
-      else pos = n_fast + (uint32_t)__popcll(m_multi & lt);
+      else pos = n_rest + n_one + (uint32_t)__popcll(m_multi & lt);
       perm[pos] = (uint8_t)lane;
-    }
-    for (unsigned long long mm = m_multi; mm; mm &= mm - 1ull) {
-      const uint32_t rr = (uint32_t)__builtin_ctzll(mm);
-      const uint32_t nit = ((meta_rows[rr * 2 + 1].y & 0xFFFFu) + 7u) / 8u;
-      for (uint32_t c0 = 0; c0 < nit; c0 += 64u) {
-        const uint32_t cnt = min(64u, nit - c0);
-        if (nslow + cnt > SLOW_CAP) flush_slow();
-        if (lane < cnt) slow_list[nslow + lane] = rr | ((c0 + lane) << 8);
-        nslow += cnt;
-      }
-      if (lane == 0u) meta_rows[rr * 2].x = 0xFFFFFFFFu;  // its last item is not parked in the row
     }
     wave_lds_sync();
     const uint32_t n_items = n_fast * TI, nmain = STREAM ? (n_items + 63u) / 64u : (n_fast + RPI - 1u) / RPI;
-    unsigned long long more = __ballot(items > TI && nev_l < 2u);
+    unsigned long long more = __ballot(items > TI);
     uint32_t cb = TI;
     // one item per lane; windows with a non-ACGT base (or, DIAG, a substitution) are queued for the
     // generic code.  Two call sites -- the fixed map and the long-read tail -- so that the per-lane
@@ -1093,8 +1088,33 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
                         uint32_t o1, uint32_t a1, uint32_t k1_, uint32_t c_idle) {
       const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
       const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+      // what the read's sequencing indels mean for this item (see fast_item)
+      const uint32_t nev_r = active ? ((m1.y >> 16) & 0x3Fu) : 0u;
+      int d0 = 0;
+      uint32_t n_in = nev_r == 1u ? 1u : 0u, ew_in = m1.w, tj_in = m1.w & 0xFFFFu;
+      if (__ballot(nev_r >= 2u) != 0ull) {
+        if (nev_r >= 2u) {
+          // walk the event list like slow_codes does: shift = output index - template index so far
+          const uint32_t* ev = B.events + ((size_t)m * B.n_slots + (g * G + r)) * SG_MAX_EVENTS;
+          const int p_lo = (int)(8u * c) - 2, p_hi = (int)(8u * c) + 7;  // positions whose source bases the item uses
+          int shift = 0;
+          n_in = 0;
+          for (uint32_t k = 0; k < nev_r; k++) {
+            const uint32_t w = ev[k];
+            const int j = (int)(w & 0xFFFFu), len = (int)((w >> 16) & 0x7FFFu);
+            const bool del = (w >> 31) != 0;
+            const int pe = j + shift;  // output position of template base j
+            if (del ? pe <= p_lo : pe + len < p_lo) { shift += del ? -len : len; continue; }  // wholly before the item
+            if (del ? pe > p_hi : pe >= p_hi) break;                                              // this and the rest: after it
+            if (n_in == 0u) { d0 = -shift; ew_in = (w & 0xFFFF0000u) | (uint32_t)pe; tj_in = (uint32_t)j; }
+            n_in++;
+            shift += del ? -len : len;
+          }
+          if (n_in == 0u) d0 = -shift;
+        }
+      }
       const bool slow = fast_item<PAIRED, DIAG, STREAM>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
-                                          o1, a1, k1_, meta_rows + r * 2);
+                                          o1, a1, k1_, meta_rows + r * 2, d0, n_in, ew_in, tj_in);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
