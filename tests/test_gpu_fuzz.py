@@ -39,6 +39,14 @@ def _make(rng, wd, extended=False):
         if rows:
             cases._write(os.path.join(wd, "snp.txt"), rows)
             kv["snp"] = os.path.join(wd, "snp.txt")
+    if extended and rng.random() < 0.35:   # another read length / indel rate on the same tables
+        src = {v: k for k, v in cases.PROFILES.items()}[os.path.basename(kv["profile"])]
+        base_len = {"xten": 151, "hs2500": 125, "hs2000": 75, "gaiix": 74}[src]
+        prof2 = os.path.join(wd, "derived.profile")
+        cases.derive_profile(src, prof2, read_length=rng.choice([52, 60, base_len + 9, 2 * base_len + 1, 400, 700]),
+                             indel_scale=rng.choice([None, None, 3.0, 12.0]))
+        kv["profile"] = prof2
+        kv["insertSize"] = max(kv["insertSize"], 900)
     if extended:
         if rng.random() < 0.4 and big[1] >= 90000:   # exome: BED targets on the largest contig
             cases._write(os.path.join(wd, "targets.bed"), cases._bed(big[0][3:] if rng.random() < 0.5 else big[0], big[1], rng.randrange(1, 99), rng.choice([3, 20, 60])))
@@ -64,7 +72,7 @@ def _seeds():
     if env:
         a, b = env.split("-")
         return list(range(int(a), int(b) + 1))
-    return list(range(101, 149)) + list(range(201, 241))
+    return list(range(101, 149)) + list(range(201, 261))
 
 
 @pytest.mark.timeout(180)
