@@ -227,6 +227,23 @@ struct Profile {
   int N = 4, kmer = 0, bins = 0, readLength = 0, kmerCount = 0;
   int minQ = 33, maxQ = 126, nQual = 94;
   double insertRate = 0, delRate = 0, stdISize = 0, gcStd = 0;
+  uint64_t cntIns = 0, cntDel = 0;  // philox mode: see ReadCtx::indel_event (set by countIndelDraws)
+  void countIndelDraws() {
+    // number of 32-bit draws x with x/2^32 <= insertRate, resp. x/2^32 < delRate/(1-insertRate): both
+    // predicates are monotone in x, so a bisection over [0, 2^32] finds the exact counts
+    const double dthr = delRate / (1 - insertRate);
+    auto count = [&](bool strict, double thr) {
+      uint64_t lo = 0, hi = 1ull << 32;  // predicate true for x < result
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const double v = (double)mid / 4294967296.0;
+        if (strict ? v < thr : v <= thr) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    cntIns = count(false, insertRate);
+    cntDel = count(true, dthr);
+  }
   vector<double> insFreqs, delFreqs, insCdf, delCdf;
   vector<string> kmers;
   map<string, int> kmerIndex;       // stands for the KmerIndex trie (Profile.h:18-23)
@@ -463,6 +480,7 @@ struct Profile {
     load(file);
     normParas();
     initCDFs(rng);
+    countIndelDraws();
   }
   int maxInsertSize() const { return iSizeAlphabet.empty() ? insertSize : iSizeAlphabet.back(); }
 
@@ -493,15 +511,27 @@ struct ReadCtx {
   uint32_t slot;   // pair slot in batch (philox)
   int mate;        // 0: read 1 (or SE), 1: read 2
   uint32_t ctx24() const { return ((uint32_t)mate << 23) | (batch & 0xFFFFu); }
-  uint32_t indel(int j, int which) {  // which: 0 insert test, 1 deletion test  (real stream)
-    if (!rng->philox) return rng->realGen();
-    // One 32-bit uniform = two independent 16-bit halves: the high halves of four template positions
-    // share the words of call (j/4, c2 = 0), the low halves those of call (j/4, c2 = 1) -- so that a
-    // consumer can decide `x <= T` from the first call alone unless its high half equals T's.
-    const uint32_t hw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 2), 0, j & 3);
-    const uint32_t lw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 2), 1, j & 3);
-    const uint32_t hi = which == 0 ? hw >> 16 : hw & 0xFFFFu, lo = which == 0 ? lw >> 16 : lw & 0xFFFFu;
-    return (hi << 16) | lo;
+  uint32_t indel(int j, int which) {  // which: 0 insert test, 1 deletion test  (real stream; mt mode only)
+    (void)j; (void)which;
+    return rng->realGen();
+  }
+  // philox mode: the insert test and the deletion test of template position j decided by ONE 64-bit
+  // uniform x64 with exactly the joint distribution of the reference's two 32-bit draws
+  // (Profile.cpp:1560-1570): with cntIns = #{x : x/2^32 <= insertRate} and cntDel = #{x : x/2^32 <
+  // delRate/(1-insertRate)}, P(insert) = cntIns/2^32 and P(delete) = (1 - cntIns/2^32) * cntDel/2^32, so
+  //   insert  iff  x64 <  cntIns * 2^32,        delete  iff  cntIns * 2^32 <= x64 < cntIns * 2^32 + (2^32 - cntIns) * cntDel.
+  // x64 = head16 << 48 | tail48: the heads of eight positions are the 16-bit halves of call (j/8, c2 = 0)
+  // (word p/2, low half for even p), the tails of positions 2q, 2q+1 the low 48 bits of words (0,1) and
+  // (2,3) of call (j/8, c2 = 1 + q) -- a consumer needs the tail only when the head sits on a boundary.
+  int indel_event(int j, uint64_t cntIns, uint64_t cntDel) {  // 0 none, 1 insertion, 2 deletion
+    const uint32_t p = (uint32_t)j & 7u;
+    const uint32_t hw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 0, p >> 1);
+    const uint64_t head = (hw >> (16u * (p & 1u))) & 0xFFFFu;
+    const uint32_t t0 = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 1u + (p >> 1), (p & 1u) * 2u);
+    const uint32_t t1 = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 1u + (p >> 1), (p & 1u) * 2u + 1u);
+    const uint64_t x64 = (head << 48) | ((uint64_t)(t1 & 0xFFFFu) << 32) | t0;
+    const uint64_t a64 = cntIns << 32, b64 = a64 + ((1ull << 32) - cntIns) * cntDel;
+    return x64 < a64 ? 1 : (x64 < b64 ? 2 : 0);
   }
   uint32_t aux(int j, int f, bool intStream) {  // f=0 indel length (real), f>=1 inserted base f-1 (int)
     if (!rng->philox) return intStream ? rng->intGen() : rng->realGen();
@@ -527,15 +557,25 @@ static int predict(const Profile& P, const char* refSeq, int n, int isRead1, Rea
     vector<int>& baseIndxs = indelBaseIndxs[j];
     baseIndxs.clear();
     int k = 0;
-    double p = u32ToDouble(rc.indel(j, 0), 0, 1);
-    if (p <= P.insertRate) {
+    bool isIns, isDel = false;
+    if (rc.rng->philox) {
+      const int ev = rc.indel_event(j, P.cntIns, P.cntDel);
+      isIns = ev == 1;
+      isDel = ev == 2;
+    } else {
+      double p = u32ToDouble(rc.indel(j, 0), 0, 1);
+      isIns = p <= P.insertRate;
+      if (!isIns) {
+        p = u32ToDouble(rc.indel(j, 1), 0, 1);
+        isDel = p < P.delRate / (1 - P.insertRate);
+      }
+    }
+    if (isIns) {
       int len = randIndxFrom(rc.aux(j, 0, false), P.insCdf.data(), (int)P.insCdf.size());
       for (int i = 0; i < len; i++) baseIndxs.push_back((int)u32ToInteger(rc.aux(j, 1 + i, true), 0, N - 1));
       k = len;
-    } else {
-      p = u32ToDouble(rc.indel(j, 1), 0, 1);
-      if (p < P.delRate / (1 - P.insertRate))
-        k = randIndxFrom(rc.aux(j, 0, false), P.delCdf.data(), (int)P.delCdf.size());
+    } else if (isDel) {
+      k = randIndxFrom(rc.aux(j, 0, false), P.delCdf.data(), (int)P.delCdf.size());
     }
     if (baseIndxs.empty() && k > 0) {
       k = std::min(n - j, k);

@@ -40,7 +40,8 @@ enum PhiloxKind : uint32_t {
   KIND_HAP = 1,    // c0 = segment ordinal in (popu,chr), c1 = draw index            -> v[0]
   KIND_GC = 2,     // c0 = window ordinal in segment, c1 = attempt, c2 = seg ordinal -> v[0],v[1]
   KIND_PLAN = 3,   // c0 = window index in batch, c1 = attempt        -> [pos, isz, strand, -]
-  KIND_INDEL = 4,  // c0 = pair slot, c1 = j/4, c2 = 0 high / 1 low halves   -> word k = ins(j0+k)<<16 | del(j0+k)  (16-bit halves)
+  KIND_INDEL = 4,  // c0 = pair slot, c1 = j/8, c2 = 0: 16-bit heads of the eight positions' 64-bit indel draws (word p/2);
+                   //                            c2 = 1+q: 48-bit tails of positions 2q (words 0,1) and 2q+1 (words 2,3)
   KIND_AUX = 5,    // c0 = pair slot, c1 = j, c2 = blk                -> flat draw f=4*blk+lane: f=0 length, f>=1 inserted base f-1
   KIND_BASE = 6,   // c0 = pair slot, c1 = i/2                        -> [sub(i0), qual(i0), sub(i0+1), qual(i0+1)]
 };

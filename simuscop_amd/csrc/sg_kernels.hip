@@ -202,38 +202,37 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   uint32_t nev = 0, first_ev = 0;
   uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
   const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
-  // Insert / deletion tests of four template positions per Philox call: word k of call (c, 0) holds the
-  // HIGH 16 bits of ins(4c+k) and del(4c+k), word k of call (c, 1) the low 16 bits.  `x <= T` is decided
-  // by the high half unless it equals T's (2 in 65536), so the second call is rare.
-  const uint32_t ThiI = P.Tins >> 16, TloI = P.Tins & 0xFFFFu, ChiD = P.Cdel >> 16, CloD = P.Cdel & 0xFFFFu;
-  for (int c = 0; 4 * c < L; c++) {
-    if (4 * c + 3 < j) continue;  // all four positions were consumed by a deletion
+  // The insert test and the deletion test of a template position (Profile.cpp:1560-1570: two 32-bit draws,
+  // P(ins) = cI / 2^32, P(del) = (1 - cI / 2^32) * cD / 2^32) are decided by ONE 64-bit uniform with exactly
+  // that joint distribution:  ins iff x64 < A,  del iff A <= x64 < B,  A = cI * 2^32, B = A + (2^32 - cI) * cD.
+  // x64 = head16 << 48 | tail48; the heads of eight positions are the halves of the four words of call (c, 0),
+  // the tail (call (c, 1 + p/2)) is needed only when a head equals the head of A or of B (2 in 65536).  A call
+  // ends after eight compares unless some lane of the wave has a head at or below B's (a quarter of a wave's
+  // calls, almost always a real event); then only the flagged positions are walked.
+  const uint64_t cI = (uint64_t)P.Tins + 1ull, A64 = cI << 32, B64 = A64 + ((1ull << 32) - cI) * (uint64_t)P.Cdel;
+  const uint32_t hA = (uint32_t)(A64 >> 48), hB = (uint32_t)(B64 >> 48);
+  for (int c = 0; 8 * c < L; c++) {
+    if (8 * c + 7 < j) continue;  // all eight positions were consumed by a deletion
     uint32_t x[4];
     philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
-    // 99.5 % of a lane's calls have no position whose high half reaches a threshold's high half; a wave
-    // (64 reads) has one in about a quarter of its calls, almost always a real event.  Only the positions
-    // some lane flagged are walked, and the low halves are fetched only by a lane whose high half EQUALS
-    // a threshold's (2 in 65536).
-    bool cand[4];
-    bool any = false;
+    uint32_t cand = 0;
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-      cand[h] = (x[h] >> 16) <= ThiI || (x[h] & 0xFFFFu) <= ChiD;
-      any |= cand[h];
-    }
-    if (__ballot(any) == 0ull) continue;
+    for (int p = 0; p < 8; p++) cand |= (uint32_t)(((x[p >> 1] >> (16 * (p & 1))) & 0xFFFFu) <= hB) << p;
+    if (__ballot(cand != 0u) == 0ull) continue;
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-      if (__ballot(cand[h]) == 0ull) continue;
-      const int jj = 4 * c + h;
-      if (!cand[h] || jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
-      const uint32_t hi_i = x[h] >> 16, hi_d = x[h] & 0xFFFFu;
-      bool is_ins = hi_i < ThiI, is_del = hi_d < ChiD;
-      if (hi_i == ThiI || hi_d == ChiD) {
+    for (int p = 0; p < 8; p++) {
+      if (__ballot((cand >> p) & 1u) == 0ull) continue;
+      const int jj = 8 * c + p;
+      if (!((cand >> p) & 1u) || jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
+      const uint32_t head = (x[p >> 1] >> (16 * (p & 1))) & 0xFFFFu;
+      bool is_ins = head < hA, is_del = head > hA && head < hB;
+      if (head == hA || head == hB) {
         uint32_t y[4];
-        philox4x32_10(t + B.slot_offset, (uint32_t)c, 1, c3, B.k0, B.k1, y);
-        if (hi_i == ThiI) is_ins = (y[h] >> 16) <= TloI;
-        if (hi_d == ChiD) is_del = (y[h] & 0xFFFFu) < CloD;
+        philox4x32_10(t + B.slot_offset, (uint32_t)c, 1u + (uint32_t)(p >> 1), c3, B.k0, B.k1, y);
+        const uint64_t tail = (p & 1) ? ((uint64_t)(y[3] & 0xFFFFu) << 32) | y[2] : ((uint64_t)(y[1] & 0xFFFFu) << 32) | y[0];
+        const uint64_t x64 = ((uint64_t)head << 48) | tail;
+        is_ins = x64 < A64;
+        is_del = !is_ins && x64 < B64;
       }
       if (is_ins) {
         uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
