@@ -160,6 +160,7 @@ def load_host():
     lib.simu_default_options.argtypes = [C.POINTER(SimuOptions)]
     lib.simu_default_options.restype = None
     lib.simu_run.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(SimuStats), C.c_char_p, C.c_size_t]
+    lib.simu_selftest_haplotypes.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t]
     lib.simu_open.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(vp), C.c_char_p, C.c_size_t]
     lib.simu_close.argtypes = [vp]
     lib.simu_close.restype = None

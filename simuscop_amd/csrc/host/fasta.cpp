@@ -282,6 +282,13 @@ void Fasta::open(const std::string& ref_file) {
   }
   fclose(fp);
   if (names.empty()) throw Error("ERROR: reference sequence cannot be empty!");
+  contigs.clear(); contig_of.clear();
+  for (const std::string& k : names) {  // index rows (lengths only: no file offsets in this mode)
+    contig_of[k] = (uint32_t)contigs.size();
+    FastaContig row;
+    row.length = seqs.at(k).size();
+    contigs.push_back(row);
+  }
 }
 
 }  // namespace simu

@@ -638,6 +638,61 @@ extern "C" int simu_run(const char* config_path, const simu_options* opt, simu_s
   }
 }
 
+extern "C" int simu_selftest_haplotypes(const char* config_path, uint64_t seed, char* err, size_t err_len) {
+  auto set_err = [&](const std::string& m) {
+    if (err && err_len) { strncpy(err, m.c_str(), err_len - 1); err[err_len - 1] = '\0'; }
+  };
+  try {
+    simu::Config cfg;
+    cfg.load(config_path ? config_path : "");
+    // two genomes over the same inputs: strings and copy lists (the host FASTA parser serves both)
+    simu::Genome gs(cfg), gp(cfg);
+    for (simu::Genome* g : {&gs, &gp}) { g->load_data(); g->generate_segments(); }
+    gp.device_haps = true;  // after load_data: the reference stays on the host, only build_chains changes
+    for (const std::string& popu : cfg.popu_names)
+      for (const std::string& chr : gs.chromosomes) {
+        gs.build_chains(popu, chr, seed);
+        gp.build_chains(popu, chr, seed);
+        const simu::ChromPlan& a = gs.plans[popu][chr];
+        const simu::ChromPlan& b = gp.plans[popu][chr];
+        const std::string& contig = gp.fa.seqs.at(chr);
+        for (size_t h = 0; h < a.chains.size(); h++) {
+          if (a.chains[h].size() != b.chain_len[h])
+            throw simu::Error("haplotype " + std::to_string(h) + " of " + popu + "/" + chr + ": lengths " +
+                              std::to_string(a.chains[h].size()) + " vs " + std::to_string(b.chain_len[h]));
+          std::string m(b.chain_len[h], '?');
+          uint64_t covered = 0;
+          for (const sg_hap_piece& p : b.pieces) {
+            if (p.chain != h) continue;
+            const char* src = p.kind ? b.literals.data() + p.src : contig.data() + p.src;
+            for (uint32_t i = 0; i < p.len; i++) {
+              char c = src[i];
+              if (c >= 'a' && c <= 'z') c -= 32;
+              m[p.dst + i] = c;
+            }
+            covered += p.len;
+          }
+          if (covered != b.chain_len[h]) throw simu::Error("copy list of " + popu + "/" + chr + " does not tile haplotype " + std::to_string(h));
+          for (const sg_hap_patch& q : b.patches)
+            if (q.chain == h) { char c = (char)q.base; if (c >= 'a' && c <= 'z') c -= 32; m[q.dst] = c; }
+          if (m != a.chains[h]) {
+            size_t i = 0;
+            while (i < m.size() && m[i] == a.chains[h][i]) i++;
+            throw simu::Error("haplotype " + std::to_string(h) + " of " + popu + "/" + chr + " differs at " + std::to_string(i));
+          }
+        }
+        // same segment bookkeeping on both routes
+        for (size_t k = 0; k < a.segs.size(); k++)
+          if (a.segs[k].hap_base != b.segs[k].hap_base || a.segs[k].hap_len != b.segs[k].hap_len)
+            throw simu::Error("segment " + std::to_string(k) + " of " + popu + "/" + chr + ": haplotype offsets differ");
+      }
+    return 0;
+  } catch (const std::exception& e) {
+    set_err(e.what());
+    return 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Session API: the same driver, opened step by step so that a caller (bench.py, a multi-GPU
 // launcher) can keep the inputs resident in HBM and drive sg_sample on its own stream.

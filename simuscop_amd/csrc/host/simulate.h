@@ -55,6 +55,12 @@ int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats
 
 void simu_default_options(simu_options* opt);
 
+// CPU-only self-test of the haplotype edit lists (no GPU call): every (population, chromosome) of the config is
+// built twice -- as strings (Genome::segment_haplotypes, the reference's std::string editing) and as the copy list
+// handed to sg_build_haplotypes (Genome::segment_pieces), materialised on the host -- and compared byte for byte.
+// Returns 0 when all chains agree; otherwise 1 and a description in `err`.
+int simu_selftest_haplotypes(const char* config_path, uint64_t seed, char* err, size_t err_len);
+
 // ---- step-by-step session (bench.py / multi-GPU launcher) ----
 typedef struct simu_session simu_session;
 int simu_open(const char* config_path, const simu_options* opt, simu_session** out, char* err, size_t err_len);
