@@ -203,6 +203,7 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
     open(ref_file);
     on_device = true;
     streamed = false;
+    contigs.clear(); contig_of.clear();  // rebuilt below with the offsets of the uploaded image
     uint64_t total = 0;
     std::vector<sg_contig> tab;
     for (const std::string& k : names) {
