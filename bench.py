@@ -31,13 +31,19 @@ TESTDATA = os.path.join(ROOT, "tests", "golden", "testData")
 BYTES_PER_PAIR_FMT = "2*L haplotype bytes read + 2 FASTQ records written"
 
 
+PROFILES = {  # name -> (file, read length)
+    "xten": ("Illumina_HiSeqXTen.profile", 151), "hs2500": ("Illumina_HiSeq2500.profile", 125),
+    "hs2000": ("Illumina_HiSeq2000.profile", 75), "gaiix": ("Illumina_GenomeAnalyzerIIx.profile", 74),
+}
+
+
 def write_config(path, fasta, out_dir, coverage=30, threads=1, profile="Illumina_HiSeqXTen.profile"):
     with open(path, "w") as f:
         f.write(f"ref = {fasta}\nprofile = {os.path.join(TESTDATA, profile)}\nname = sim\noutput = {out_dir}\n"
                 f"layout = PE\nthreads = {threads}\nverbose = 0\ncoverage = {coverage}\ninsertSize = 350\n")
 
 
-def cpu_baseline(workdir, cores):
+def cpu_baseline(workdir, cores, profile="Illumina_HiSeqXTen.profile"):
     """Time the reference's CPU thread-pool path on a bounded sample of the same workload.
 
     Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
@@ -49,7 +55,7 @@ def cpu_baseline(workdir, cores):
     synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
     cfg = os.path.join(workdir, "cpu_config.txt")
     out = os.path.join(workdir, "cpu_out")
-    write_config(cfg, fa, out, threads=cores)
+    write_config(cfg, fa, out, threads=cores, profile=profile)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "simuReads")
     kind = "reference"
     if os.path.exists(ref_bin):
@@ -70,7 +76,7 @@ def cpu_baseline(workdir, cores):
     for fn in os.listdir(out):
         os.remove(os.path.join(out, fn))
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": kind,
-            "sample": f"{sample_len} bp contig, XTen PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
+            "sample": f"{sample_len} bp contig, {profile[9:-8]} PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
                       f"(whole run incl. input load, threads={cores})"}
 
 
@@ -132,6 +138,8 @@ def main():
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", default="xten", choices=sorted(PROFILES),
+                    help="sequencing profile of the workload (default: HiSeqXTen, the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
@@ -173,10 +181,10 @@ def main():
             f.write(seq[full:].tobytes() + b"\n")
     del seq
     cfg = os.path.join(workdir, "config.txt")
-    write_config(cfg, fasta, os.path.join(workdir, "out"), coverage=args.coverage)
+    write_config(cfg, fasta, os.path.join(workdir, "out"), coverage=args.coverage, profile=PROFILES[args.profile][0])
 
     sess = simuscop_amd.Session(cfg, device=local_rank, write_files=0, quiet=1, seed=0x5EED0000 + rank)
-    L = 151
+    L = PROFILES[args.profile][1]
     # ---- read-count balancing (Genome::setReadCounts) ----
     my_wl = sess.weighted_length()
     from simuscop_amd import dist as sdist
@@ -223,7 +231,7 @@ def main():
         dt_max, total_pairs = dt, float(pairs)
 
     if rank == 0:
-        default_workload = args.contig_len == CHR20_LEN and args.coverage == 30
+        default_workload = args.contig_len == CHR20_LEN and args.coverage == 30 and args.profile == "xten"
         pairs_per_step = pairs / args.steps
         emit_ms = kms["emit"] / args.steps            # emit_fast_kernel alone (HIP events around that launch)
         slow_ms = kms["emit_slow"] / args.steps       # emit_slow_kernel: the items it queued
@@ -245,8 +253,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU" + (" (GRCh38 chr20 length)" if args.contig_len == CHR20_LEN else "") + ", HiSeqXTen profile "
-                                   f"(151 bp), PE, {args.coverage}x, insertSize 350",
+            "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU" + (" (GRCh38 chr20 length)" if args.contig_len == CHR20_LEN else "") + f", {PROFILES[args.profile][0][:-8]} profile "
+                                   f"({L} bp), PE, {args.coverage}x, insertSize 350",
                        "pairs_per_step_per_gpu": pairs_per_step, "parallelism": f"{world} x 1 chromosome shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
@@ -264,7 +272,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             try:
-                out["cpu_baseline"] = cpu_baseline(workdir, cores)
+                out["cpu_baseline"] = cpu_baseline(workdir, cores, PROFILES[args.profile][0])
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)
