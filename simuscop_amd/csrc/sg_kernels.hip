@@ -974,6 +974,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
   uint8_t* perm_all = (uint8_t*)(slow_all + EMIT_WAVES * SLOW_CAP);
+  uint16_t* ovf_all = (uint16_t*)(perm_all + EMIT_WAVES * 64);  // items just past the stream map (read | item << 8)
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   // staging with the fast kernel's digit / base-order permutations
   for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
@@ -999,15 +1000,17 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
   uint8_t* perm = perm_all + wv * 64;
+  uint16_t* ovf = ovf_all + wv * 128;
 
   // Two lane -> (read, item) maps over the first TI items of a group's reads:
-  //   STREAM  G = 64 reads; their items form one stream, 64 per step: lane l of step s does stream item
+  //   STREAM  G = 63 reads; their items form one stream, 64 per step: lane l of step s does stream item
   //           i = 64 s + l = item i % TI of the (i / TI)-th read in step order; every lane busy whatever TI is;
   //   fixed   RPI = 64 / TI whole reads per step, lane = (read in step, item): constant per lane, cheaper per
   //           step, but 64 - RPI * TI lanes idle (7 at TI 19).
   // map_arg = ceil-reciprocal of TI (STREAM) or RPI (fixed).  launch_emit picks by measurement.
   const uint32_t inv_TI = map_arg, RPI = STREAM ? 1u : map_arg;
-  const uint32_t G = STREAM ? 64u : RPI * (64u / RPI);
+  // STREAM: 63 reads, so that TI steps (64 TI item slots) hold their 63 TI map items plus up to TI appended ones
+  const uint32_t G = STREAM ? 63u : RPI * (64u / RPI);
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
   const uint32_t sub = lane / TI, c_lane = lane - sub * TI;
   const bool lane_ok = sub < RPI;
@@ -1076,9 +1079,28 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       else pos = n_rest + n_one + (uint32_t)__popcll(m_multi & lt);
       perm[pos] = (uint8_t)lane;
     }
+    // STREAM: TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to
+    // the end of the stream (they fill lanes of the last step that would idle anyway); only reads longer
+    // than that take steps of their own below.
+    uint32_t n_ovf = 0;
+    unsigned long long more;
+    if (STREAM) {
+      const uint32_t extra = items > TI ? items - TI : 0u;
+      const bool small = extra == 1u || extra == 2u;
+      const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
+      if (small) {
+        const uint32_t o = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+        ovf[o] = (uint16_t)(lane | (TI << 8));
+        if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
+      }
+      n_ovf = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+      more = __ballot(extra > 2u);
+    } else {
+      more = __ballot(items > TI);
+    }
     wave_lds_sync();
-    const uint32_t n_items = n_fast * TI, nmain = STREAM ? (n_items + 63u) / 64u : (n_fast + RPI - 1u) / RPI;
-    unsigned long long more = __ballot(items > TI);
+    const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
+    const uint32_t nmain = STREAM ? (n_stream + 63u) / 64u : (n_fast + RPI - 1u) / RPI;
     uint32_t cb = TI;
     // one item per lane; windows with a non-ACGT base (or, DIAG, a substitution) are queued for the
     // generic code.  Two call sites -- the fixed map and the long-read tail -- so that the per-lane
@@ -1124,9 +1146,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       for (uint32_t step = 0; step < nmain; step++) {  // the item stream, 64 items per step
         if (nslow > SLOW_CAP - 64u) flush_slow();
         const uint32_t i = step * 64u + lane;
-        const bool ok = i < n_items;
-        const uint32_t ri = __umul24(i, inv_TI) >> 20, c = i - __umul24(ri, TI);  // i / TI, i % TI (exact: i * TI < 2^20)
-        const uint32_t r = perm[ok ? ri : 0u];
+        const bool ok = i < n_stream, in_map = i < n_items;
+        const uint32_t ri = __umul24(i, inv_TI) >> 20;  // i / TI (exact: i * TI < 2^20)
+        const uint32_t e = ovf[(ok && !in_map) ? i - n_items : 0u];
+        const uint32_t r = in_map ? perm[ri] : (ok ? (e & 0xFFu) : perm[0]);
+        const uint32_t c = in_map ? i - __umul24(ri, TI) : (ok ? e >> 8 : 1u);
         const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
         const bool head = c == 0u;
         run_item(r, c, ok, m0, m1, head ? 10u : 6u, head ? 2u : 6u, head ? 0u : 20u, head ? 10u : 8u, head ? 4u : 6u, head ? 4u : 20u, c);
@@ -1342,7 +1366,8 @@ static EmitLds emit_lds(const DevProfile& P) {
   e.sub_rows = kmer_count * (uint32_t)P.bins;
   e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
   e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64;
+  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 +
+                       (size_t)EMIT_WAVES * 128 * 2;
   const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
   const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
   e.sub_lds = fixed + sub_b <= kLdsBytes;
@@ -1394,14 +1419,15 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
   // straight-line kernel, item-stream map by default: measured on the four shipped profiles it ties with the
   // fixed map on XTen (4.91 vs 4.97 ms) and wins clearly with the diagonal-row variant (7.1 vs 9.2 ms
   // HiSeq2500, 7.4 vs 10.5 ms HiSeq2000 / GAIIx).  SG_EMIT_MAP=fixed selects the other map (diagnostics).
-  // three bases of slack in TI: a read that gained up to 3 bases still fits the map (a longer one costs a whole
-  // extra step with a single busy lane; at TI = ceil(L/8) that happened for 5 % of the XTen reads)
-  uint32_t TIf = ((uint32_t)P.L + 3u + 7u) / 8u;
-  if (TIf > 64u) TIf = 64u;
-  const uint32_t RPIf = 64u / TIf;
   bool stream = true;
   if (const char* e = getenv("SG_EMIT_MAP")) stream = e[0] == 's';
-  const uint32_t Gf = stream ? 64u : RPIf * (64u / RPIf);
+  // fixed map: three bases of slack in TI (a read that outgrows the map costs a whole extra step with one
+  // busy lane; at TI = ceil(L/8) that happened to 5 % of the XTen reads).  The stream map needs none: such
+  // items are appended to the stream.
+  uint32_t TIf = ((uint32_t)P.L + (stream ? 0u : 3u) + 7u) / 8u;
+  if (TIf > 64u) TIf = 64u;
+  const uint32_t RPIf = 64u / TIf;
+  const uint32_t Gf = stream ? 63u : RPIf * (64u / RPIf);
   const uint32_t fneed = ((B.n_slots + Gf - 1u) / Gf + EMIT_WAVES - 1) / EMIT_WAVES;
   uint32_t fgx = (uint32_t)cus / nm;
   if (fgx < 1) fgx = 1;
