@@ -1024,7 +1024,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   // eight.  (Measured on C2: FETCH_SIZE and time unchanged -- the haplotype bytes were already fetched about
   // once, the read-side traffic is the per-read rows -- so this is tidiness, not a speed-up.)
   const uint32_t bx = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  for (uint32_t g = bx * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
+  // first group by position, further groups from a per-mate counter: waves that drew cheap groups (few
+  // event reads) take more of them, so the grid drains evenly
+  uint32_t* next_group = (uint32_t*)(B.totals + 5) + m;
+  for (uint32_t g = bx * EMIT_WAVES + wv; g < ngroups;) {
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
@@ -1209,6 +1212,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
     }
     wave_lds_sync();
+    uint32_t nx = 0;
+    if (lane == 0u) nx = atomicAdd(next_group, 1u);
+    g = gridDim.x * EMIT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
   }
 }
 
