@@ -44,7 +44,7 @@ struct DevDeflate {
   const uint8_t* text; uint64_t bytes; uint32_t n_chunks;
   const uint32_t* code; const uint32_t* prefix; uint32_t prefix_words, prefix_bits;
   const uint32_t* crc_tab; const uint32_t* crc_shift; uint32_t crc_init_full, crc_init_last;
-  uint32_t* msize; const uint64_t* moff; uint8_t* out;
+  uint32_t* next; uint32_t* msize; const uint64_t* moff; uint8_t* out;
 };
 void launch_gz_hist(const uint8_t* text, uint64_t bytes, unsigned long long* hist, hipStream_t s);
 void launch_gz_size(const void* d, uint32_t n_chunks, hipStream_t s);
@@ -490,6 +490,7 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     D.crc_init_full = plan.crc_init_full;
     const uint64_t last = bytes - (uint64_t)(n_chunks - 1) * sg::kGzChunk;
     D.crc_init_last = sg::crc_advance(plan, 0xFFFFFFFFu, last);
+    D.next = (uint32_t*)(wk + 2048 + 16);  // inside the zeroed head of the work buffer
     D.msize = (uint32_t*)(wk + off_msize);
     D.moff = (const uint64_t*)(wk + off_moff);
     D.out = nullptr;

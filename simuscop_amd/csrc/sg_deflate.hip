@@ -29,6 +29,7 @@ struct DevDeflate {
   const uint32_t* crc_tab;    // [4][256]
   const uint32_t* crc_shift;  // [kGzLevels][32]
   uint32_t crc_init_full, crc_init_last;
+  uint32_t* next;             // [2] chunk counter of the encode kernel at [1] (zeroed by the host)
   uint32_t* msize;            // [n_chunks] member bytes
   const uint64_t* moff;       // [n_chunks] member offsets
   uint8_t* out;
@@ -130,7 +131,9 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
   for (uint32_t i = lane; i < 1024; i += kGzThreads) crc_tab[i] = D.crc_tab[i];
   for (uint32_t i = lane; i < kGzLevels * 32; i += kGzThreads) crc_shift[i] = D.crc_shift[i];
   __syncthreads();
-  for (uint32_t c = blockIdx.x; c < D.n_chunks; c += gridDim.x) {
+  __shared__ uint32_t next_c;
+  // chunks beyond a workgroup's first come from a counter (CUs do not all run at the same speed)
+  for (uint32_t c = blockIdx.x; c < D.n_chunks;) {
     const uint64_t left = D.bytes - (uint64_t)c * kGzChunk;
     const uint32_t n = left < kGzChunk ? (uint32_t)left : kGzChunk;
     const uint32_t msize = D.msize[c];
@@ -217,6 +220,9 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
         for (uint32_t b = i; b < msize; b++) dst[b] = sb[b];
       }
     }
+    if (lane == 0) next_c = gridDim.x + atomicAdd(D.next + 1, 1u);
+    __syncthreads();
+    c = next_c;
     __syncthreads();
   }
 }
