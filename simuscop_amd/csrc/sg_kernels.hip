@@ -715,7 +715,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
   const uint32_t sub = lane / TI, c_lane = lane - sub * TI;  // fixed lane -> (read in iteration, item)
   const bool lane_ok = sub < RPI;
 
-  for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups; g += gridDim.x * EMIT_WAVES) {
+  // first group by position, further ones from a per-mate counter (its own: this kernel also re-emits a
+  // batch after emit_fast_kernel has run, see sg_result)
+  uint32_t* next_group = (uint32_t*)(B.totals + 6) + m;
+  for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups;) {
     // ================= phase 0: lane = read: its 32-byte row (coalesced) into LDS =================
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
@@ -767,6 +770,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
     }
 
     wave_lds_sync();  // the next group's phase 0 rewrites the metadata rows
+    uint32_t nx = 0;
+    if (lane == 0u) nx = atomicAdd(next_group, 1u);
+    g = gridDim.x * EMIT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
   }
 }
 
