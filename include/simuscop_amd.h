@@ -236,13 +236,24 @@ int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
  * are identical either way (Profile::predict, Profile.cpp:1520-1650 has one code path).          */
 int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
 /* Which emit kernel the loaded profile gets (after sg_load_profile): 0 generic (tables that do not fit
- * LDS, k-mer sizes other than 3), 1 straight-line kernel with the whole quality table in LDS,
- * 2 straight-line kernel with the (reference == called) quality rows in LDS (wide quality alphabets). */
+ * LDS, k-mer sizes other than 3), 1 straight-line kernel (table image in LDS). */
 int sg_emit_variant(sg_ctx* ctx);
 
 /* Exact u32 form of the reference's inverse-CDF draw, exposed for tests: number of 32-bit draws
  * x for which randIndx's `r <= c` holds (r = 2.2204e-16 + (1-2.2204e-16)*x/2^32).               */
 uint64_t sg_cdf_count_le(double c);
+
+/* The per-base sampling tables, exposed for tests (host code, no GPU needed).  A CDF row partitions the 2^32 draws
+ * into integer counts per outcome (sg_cdf_count_le differences); the engine samples through two rearrangements that
+ * keep every count:
+ *   sg_sub_row_identity_first  substitution row (Profile::getSubBaseIndx1/2, Profile.cpp:1527-1554): outcomes in the
+ *                              order [cd, the other base indexes ascending], cum[i] = draws of order[0..i];
+ *   sg_alias_row               quality row (Profile::getBaseQuality, Profile.cpp:1576-1580) as 2^lgW alias columns:
+ *                              draw x -> column x >> (32 - lgW), symbol lo[col] if (x & (2^(32-lgW) - 1)) < thr[col] else
+ *                              hi[col];  sg_row_symbols = number of symbols with a non-zero count (columns needed).   */
+int sg_sub_row_identity_first(const double cdf4[4], int cd, uint64_t cum[3], uint8_t order[4]);
+uint32_t sg_row_symbols(const double* cdf, int n);
+int sg_alias_row(const double* cdf, int n, uint32_t lgW, uint32_t* thr, uint8_t* lo, uint8_t* hi);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,33 @@ static inline int randIndxFrom(uint32_t x, const double* cdf, int ac) {
   return ac - 1;
 }
 
+// Philox mode only.  randIndx's predicate `r <= c` (MyDefine.cpp:176-184) is monotone in the 32-bit draw x, so for
+// every fp64 CDF value c it holds exactly for the draws x < countLe(c): countLe(c) = #{x : r(x) <= c}, by bisection
+// on the reference's own fp64 expression.  A CDF row therefore partitions the 2^32 draws into integer masses
+//   n[k] = countLe(cdf[k]) - countLe(cdf[k-1])   (k < ac-1),   n[ac-1] = 2^32 - countLe(cdf[ac-2])
+// (the fall-through `return ac-1`), and ANY map from a uniform 32-bit draw to outcomes that gives outcome k exactly
+// n[k] draws samples the reference's distribution exactly.  The philox mode uses two such maps:
+// an identity-first order for substitutions and Walker/Vose alias columns for qualities.
+static uint64_t countLe(double c) {
+  uint64_t lo = 0, hi = 1ull << 32;  // predicate true for x < result
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (u32ToDouble((uint32_t)mid, ZERO_FINAL, 1) <= c) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+static void rowMasses(const double* cdf, int ac, vector<uint64_t>& n) {
+  n.assign(ac, 0);
+  uint64_t prev = 0;
+  for (int k = 0; k + 1 < ac; k++) {
+    uint64_t c = countLe(cdf[k]);
+    if (c < prev) c = prev;  // a CDF is non-decreasing; guards against a malformed row
+    n[k] = c - prev;
+    prev = c;
+  }
+  n[ac - 1] = (1ull << 32) - prev;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Profile (lib/profile/Profile.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -243,6 +270,92 @@ struct Profile {
     };
     cntIns = count(false, insertRate);
     cntDel = count(true, dthr);
+  }
+  // ---- philox mode: integer sampling tables (built from the fp64 CDFs by buildIntegerTables) ----
+  // Substitution row (kmerIndx, bin): outcomes in the order o = [cd, the other base indexes ascending], cd = index of the
+  // context's last base (the reference base itself); cumulative masses c0 <= c1 <= c2 of o[0..2]:
+  //   j = #{i : xs >= c_i},  k = o[j]          -- "no substitution" is the single test xs < c0.
+  // Quality row (refIndx*N + k, bin): alias columns.  W = 2^lgW >= the largest number of symbols with mass in any row
+  // (>= 4), C = 2^32 / W draws per column; column col holds symbol aLo for u < aThr and aHi for u >= aThr, where
+  //   col = xq >> (32 - lgW),  u = xq & (C - 1).
+  vector<uint64_t> subCum1, subCum2;  // [kmerCount * bins][3]
+  vector<uint8_t> subOrd;             // [kmerCount][4]
+  int lgW = 2;
+  vector<uint32_t> aThr;              // [N*N * bins][W], in [0, C)
+  vector<uint8_t> aLo, aHi;
+  void buildIntegerTables() {
+    vector<uint64_t> n;
+    subOrd.assign((size_t)kmerCount * 4, 0);
+    for (int i = 0; i < kmerCount; i++) {
+      const int cd = baseIndex(kmers[i][kmer - 1]);
+      uint8_t* o = &subOrd[(size_t)i * 4];
+      o[0] = (uint8_t)cd;
+      for (int k = 0, q = 1; k < N; k++) if (k != cd) o[q++] = (uint8_t)k;
+    }
+    for (int t = 0; t < 2; t++) {
+      const vector<double>& src = t == 0 ? subs1 : subs2;
+      vector<uint64_t>& dst = t == 0 ? subCum1 : subCum2;
+      dst.assign((size_t)kmerCount * bins * 3, 0);
+      if (t == 1 && !hasSub2) continue;
+      for (size_t r = 0; r < (size_t)kmerCount * bins; r++) {
+        rowMasses(src.data() + r * N, N, n);
+        const uint8_t* o = &subOrd[(r / bins) * 4];
+        uint64_t c = 0;
+        for (int i = 0; i < 3; i++) { c += n[o[i]]; dst[r * 3 + i] = c; }
+      }
+    }
+    // quality alias columns
+    const size_t qrows = (size_t)N * N * bins;
+    vector<vector<uint64_t>> masses(qrows);
+    size_t most = 1;
+    for (size_t r = 0; r < qrows; r++) {
+      rowMasses(qual.data() + r * nQual, nQual, masses[r]);
+      size_t m = 0;
+      for (uint64_t v : masses[r]) m += v != 0;
+      most = std::max(most, m);
+    }
+    lgW = 2;
+    while ((1u << lgW) < most) lgW++;
+    const uint32_t W = 1u << lgW;
+    const uint64_t C = 1ull << (32 - lgW);
+    aThr.assign(qrows * W, 0); aLo.assign(qrows * W, 0); aHi.assign(qrows * W, 0);
+    for (size_t r = 0; r < qrows; r++) {
+      // columns 0..m-1 start with the row's symbols in ascending order, the others empty
+      vector<uint64_t> mass(W, 0);
+      vector<int> sym(W, -1);
+      uint32_t m = 0;
+      for (int k = 0; k < nQual; k++) if (masses[r][k]) { mass[m] = masses[r][k]; sym[m] = k; m++; }
+      vector<uint32_t> small, large;
+      for (uint32_t c = 0; c < W; c++) (mass[c] < C ? small : large).push_back(c);
+      vector<uint64_t> thr(W, C);
+      vector<int> lo(sym), hi(sym);
+      while (!small.empty() && !large.empty()) {
+        const uint32_t sc = small.back(); small.pop_back();
+        const uint32_t g = large.back(); large.pop_back();
+        thr[sc] = mass[sc]; hi[sc] = sym[g];
+        mass[g] -= C - mass[sc];
+        (mass[g] < C ? small : large).push_back(g);
+      }
+      if (!small.empty()) throw Fail("alias construction: masses do not add up");
+      for (uint32_t c = 0; c < W; c++) {
+        // canonical form: thr in [0, C); a column of one symbol is thr = 0 with that symbol on both sides
+        if (thr[c] == C) { thr[c] = 0; hi[c] = lo[c]; }
+        if (thr[c] == 0) lo[c] = hi[c];
+        if (lo[c] < 0 || hi[c] < 0) throw Fail("alias construction: empty column left without a symbol");
+        aThr[r * W + c] = (uint32_t)thr[c]; aLo[r * W + c] = (uint8_t)lo[c]; aHi[r * W + c] = (uint8_t)hi[c];
+      }
+    }
+  }
+  int subSample(bool mate2, int kmerIndx, int binIndx, uint32_t xs) const {
+    const size_t r = (size_t)kmerIndx * bins + binIndx;
+    const uint64_t* c = (mate2 ? subCum2 : subCum1).data() + r * 3;
+    const int j = (xs >= c[0]) + (xs >= c[1]) + (xs >= c[2]);
+    return subOrd[(size_t)kmerIndx * 4 + j];
+  }
+  int qualSample(int bp, int binIndx, uint32_t xq) const {
+    const size_t r = ((size_t)bp * bins + binIndx) << lgW;
+    const uint32_t col = xq >> (32 - lgW), u = xq & ((1u << (32 - lgW)) - 1u);
+    return u < aThr[r + col] ? aLo[r + col] : aHi[r + col];
   }
   vector<double> insFreqs, delFreqs, insCdf, delCdf;
   vector<string> kmers;
@@ -481,6 +594,7 @@ struct Profile {
     normParas();
     initCDFs(rng);
     countIndelDraws();
+    if (rng.philox) buildIntegerTables();
   }
   int maxInsertSize() const { return iSizeAlphabet.empty() ? insertSize : iSizeAlphabet.back(); }
 
@@ -537,9 +651,25 @@ struct ReadCtx {
     if (!rng->philox) return intStream ? rng->intGen() : rng->realGen();
     return rng->ph(KIND_AUX, ctx24(), slot, (uint32_t)j, (uint32_t)(f >> 2), f & 3);
   }
+  // philox mode: output position i owns word i%4 of two calls, (i/4, c2 = 0) "heads" and (i/4, c2 = 1) "tails":
+  //   substitution draw xs = heads[31:16] << 16 | tails[31:16]
+  //   quality draw      xq = heads[15:0]  << 16 | tails[15:0]
+  // Both are uniform 32-bit values.  The split exists for the GPU: almost every base is decided by the heads alone
+  // (no substitution / which side of an alias column), so the tails call is made only for the rare base that needs it.
+  uint32_t cachedCall = 0xFFFFFFFFu;
+  int cachedMate = -1;
+  Philox4 heads{}, tails{};
   uint32_t base(int i, int which, bool intStream) {  // which: 0 substitution, 1 quality
     if (!rng->philox) return intStream ? rng->intGen() : rng->realGen();
-    return rng->ph(KIND_BASE, ctx24(), slot, (uint32_t)(i >> 1), 0, (i & 1) * 2 + which);
+    const uint32_t call = (uint32_t)(i >> 2), l = (uint32_t)i & 3u;
+    if (call != cachedCall || mate != cachedMate) {
+      cachedMate = mate;
+      heads = philox4x32_10(slot, call, 0, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
+      tails = philox4x32_10(slot, call, 1, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
+      cachedCall = call;
+    }
+    const uint32_t wh = heads.v[l], wt = tails.v[l];
+    return which == 0 ? (wh & 0xFFFF0000u) | (wt >> 16) : (wh << 16) | (wt & 0xFFFFu);
   }
 };
 
@@ -623,7 +753,9 @@ static int predict(const Profile& P, const char* refSeq, int n, int isRead1, Rea
     if (kmerIndx == -1) {
       k = P.baseIndex(seq[j + kmer - 1]);
     } else {
-      k = randIndxFrom(rc.base(j, 0, false), subs.data() + ((size_t)kmerIndx * binCount + binIndx) * N, N);
+      const uint32_t xs = rc.base(j, 0, false);
+      k = rc.rng->philox ? P.subSample(!(isRead1 || !P.hasSub2), kmerIndx, binIndx, xs)
+                         : randIndxFrom(xs, subs.data() + ((size_t)kmerIndx * binCount + binIndx) * N, N);
     }
     if (k == -1) {
       outBases[j] = 'N';
@@ -631,7 +763,9 @@ static int predict(const Profile& P, const char* refSeq, int n, int isRead1, Rea
     } else {
       outBases[j] = P.bases[k];
       int bp = refIndx * N + k;
-      int qi = randIndxFrom(rc.base(j, 1, false), P.qual.data() + ((size_t)bp * binCount + binIndx) * P.nQual, P.nQual);
+      const uint32_t xq = rc.base(j, 1, false);
+      int qi = rc.rng->philox ? P.qualSample(bp, binIndx, xq)
+                              : randIndxFrom(xq, P.qual.data() + ((size_t)bp * binCount + binIndx) * P.nQual, P.nQual);
       outQuals[j] = (char)(P.minQ + qi);
     }
   }
@@ -1644,6 +1778,7 @@ extern "C" int orc_profile_info(const orc_profile* h, int what) {
     case 4: return p.kmerCount; case 5: return p.nQual; case 6: return (int)p.insCdf.size();
     case 7: return (int)p.delCdf.size(); case 8: return (int)p.iSizeCdf.size(); case 9: return p.hasSub2 ? 1 : 0;
     case 10: return p.iSizeAlphabet.empty() ? p.insertSize : p.iSizeAlphabet[0];
+    case 11: return p.lgW;
   }
   return -1;
 }
@@ -1659,6 +1794,17 @@ extern "C" const double* orc_profile_array(const orc_profile* h, int which) {
     case 5: return p.iSizeCdf.empty() ? nullptr : p.iSizeCdf.data(); case 6: return p.gcMeans;
   }
   return nullptr;
+}
+extern "C" void orc_profile_sub_row(const orc_profile* h, int mate2, int kmer_indx, int bin, uint64_t cum[3], uint8_t order[4]) {
+  const orc::Profile& p = h->p;
+  const size_t r = (size_t)kmer_indx * p.bins + bin;
+  for (int i = 0; i < 3; i++) cum[i] = (mate2 ? p.subCum2 : p.subCum1)[r * 3 + i];
+  for (int i = 0; i < 4; i++) order[i] = p.subOrd[(size_t)kmer_indx * 4 + i];
+}
+extern "C" void orc_profile_alias_row(const orc_profile* h, int base_pair, int bin, uint32_t* thr, uint8_t* lo, uint8_t* hi) {
+  const orc::Profile& p = h->p;
+  const size_t r = ((size_t)base_pair * p.bins + bin) << p.lgW;
+  for (uint32_t c = 0; c < (1u << p.lgW); c++) { thr[c] = p.aThr[r + c]; lo[c] = p.aLo[r + c]; hi[c] = p.aHi[r + c]; }
 }
 extern "C" void orc_profile_kmer(const orc_profile* h, int i, char* out) {
   memcpy(out, h->p.kmers[i].data(), h->p.kmer);

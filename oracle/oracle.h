@@ -11,7 +11,10 @@
 // oracle/fakeclock.c with the same frozen time.  tests/golden/ holds md5 sums of such reference
 // runs (made by tests/golden/make_golden.py).  In RNG mode "philox" the same algorithm code draws
 // from counter-addressed Philox4x32-10 streams (oracle/philox.h) -- that is the specification the
-// HIP kernels are compared with bit for bit.
+// HIP kernels are compared with bit for bit.  Two of its draw -> outcome maps are re-arranged (identity-first
+// substitution rows, alias columns for qualities): each outcome keeps exactly the number of 32-bit draws the
+// reference's `r <= cdf[k]` scan gives it, so the sampled distributions are identical, not approximated
+// (tests/test_integer_tables.py checks the counts row by row).
 #pragma once
 #include <cstdint>
 
@@ -37,12 +40,17 @@ typedef struct orc_profile orc_profile;
 orc_profile* orc_profile_load(const char* path, int paired, int insert_size);
 void orc_profile_free(orc_profile*);
 // scalar info: 0 n_bases, 1 kmer, 2 bins, 3 read_length, 4 kmer_count, 5 n_qual, 6 n_ins,
-//              7 n_del, 8 n_isize (0 = fixed insert size), 9 has_sub2, 10 isize_min
+//              7 n_del, 8 n_isize (0 = fixed insert size), 9 has_sub2, 10 isize_min, 11 lgW (alias columns = 2^lgW)
 int orc_profile_info(const orc_profile*, int what);
 double orc_profile_rate(const orc_profile*, int which);  // 0 insertRate 1 delRate 2 stdISize 3 gcStd
 // array views (fp64, exactly the reference's in-memory CDFs): 0 insCdf 1 delCdf
 // 2 subsCdf1 [kmer_count][bins][N] 3 subsCdf2 4 qualityCdf [N*N][bins][n_qual] 5 iSizeCdf 6 gcMeans[101]
 const double* orc_profile_array(const orc_profile*, int which);
+// philox-mode integer sampling tables (oracle.cpp "integer sampling tables"):
+//   substitution row: cumulative draw counts of the outcomes order[0..2] (order[0] = the reference base itself)
+//   quality alias row: per column the threshold inside the column and the symbols below / from it
+void orc_profile_sub_row(const orc_profile*, int mate2, int kmer_indx, int bin, uint64_t cum[3], uint8_t order[4]);
+void orc_profile_alias_row(const orc_profile*, int base_pair, int bin, uint32_t* thr, uint8_t* lo, uint8_t* hi);
 // kmer strings in table order (Profile::initKmers, Profile.cpp:70-124): writes kmer chars of entry i
 void orc_profile_kmer(const orc_profile*, int i, char* out);
 

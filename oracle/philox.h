@@ -43,7 +43,8 @@ enum PhiloxKind : uint32_t {
   KIND_INDEL = 4,  // c0 = pair slot, c1 = j/8, c2 = 0: 16-bit heads of the eight positions' 64-bit indel draws (word p/2);
                    //                            c2 = 1+q: 48-bit tails of positions 2q (words 0,1) and 2q+1 (words 2,3)
   KIND_AUX = 5,    // c0 = pair slot, c1 = j, c2 = blk                -> flat draw f=4*blk+lane: f=0 length, f>=1 inserted base f-1
-  KIND_BASE = 6,   // c0 = pair slot, c1 = i/2                        -> [sub(i0), qual(i0), sub(i0+1), qual(i0+1)]
+  KIND_BASE = 6,   // c0 = pair slot, c1 = i/4, c2 = 0 heads / 1 tails; word i%4 belongs to output position i:
+                   //   substitution draw = heads[31:16] << 16 | tails[31:16], quality draw = heads[15:0] << 16 | tails[15:0]
 };
 
 }  // namespace orc

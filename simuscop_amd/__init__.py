@@ -26,6 +26,7 @@ ENGINE_SYMBOLS = [
     "sg_bgzf_eof", "sg_deflate_plan", "sg_detach_outputs", "sg_outputs_sizes", "sg_outputs_fetch",
     "sg_outputs_last_error", "sg_release_outputs", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
+    "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row",
     "sg_host_free",
 ]
 
@@ -143,6 +144,11 @@ def load_engine():
     lib.sg_emit_variant.argtypes = [vp]
     lib.sg_cdf_count_le.argtypes = [C.c_double]
     lib.sg_cdf_count_le.restype = C.c_uint64
+    lib.sg_sub_row_identity_first.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+    lib.sg_row_symbols.argtypes = [C.POINTER(C.c_double), C.c_int]
+    lib.sg_row_symbols.restype = C.c_uint32
+    lib.sg_alias_row.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8),
+                                 C.POINTER(C.c_uint8)]
     _engine = lib
     return lib
 

@@ -137,6 +137,27 @@ extern "C" {
 
 uint64_t sg_cdf_count_le(double c) { return sg::count_le(c); }
 
+int sg_sub_row_identity_first(const double cdf4[4], int cd, uint64_t cum[3], uint8_t order[4]) {
+  if (!cdf4 || !cum || !order || cd < 0 || cd > 3) return SG_ERR_INVALID;
+  const sg::SubRow r = sg::encode_sub_row_identity_first(cdf4, cd);
+  for (int i = 0; i < 3; i++) cum[i] = r.c[i];
+  for (int i = 0; i < 4; i++) order[i] = r.order[i];
+  return SG_OK;
+}
+
+uint32_t sg_row_symbols(const double* cdf, int n) { return (cdf && n > 0) ? sg::symbols_with_mass(sg::row_masses(cdf, n)) : 0u; }
+
+int sg_alias_row(const double* cdf, int n, uint32_t lgW, uint32_t* thr, uint8_t* lo, uint8_t* hi) {
+  if (!cdf || n < 1 || n > 256 || lgW < 2 || lgW > 8 || !thr || !lo || !hi) return SG_ERR_INVALID;
+  try {
+    const sg::AliasRow r = sg::build_alias_row(sg::row_masses(cdf, n), lgW);
+    for (uint32_t c = 0; c < (1u << lgW); c++) { thr[c] = r.thr[c]; lo[c] = r.lo[c]; hi[c] = r.hi[c]; }
+  } catch (const std::exception&) {
+    return SG_ERR_INVALID;
+  }
+  return SG_OK;
+}
+
 const char* sg_last_error(const sg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int sg_create(sg_ctx** out, int device, uint64_t seed) {
@@ -223,7 +244,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     if (npmax > 0xFFFF || npmax * (uint64_t)pr->bins * npmax >= (1ull << 32))
       return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: read_length * bins too large for the 32-bit bin arithmetic");
   }
-  if (pr->n_qual < 1 || pr->n_qual > 4096) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad n_qual");
+  if (pr->n_qual < 1 || pr->n_qual > 128) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: n_qual must be in 1..128 (quality symbols are 7-bit fields)");
   if (!pr->subs_cdf1 || !pr->qual_cdf || !pr->ins_cdf || !pr->del_cdf || pr->n_ins < 1 || pr->n_del < 1)
     return ctx->fail(SG_ERR_INVALID, "sg_load_profile: missing table");
   // base alphabet must be a permutation of ACGT (the kernels classify haplotype bytes by value)
@@ -246,38 +267,59 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   const int bins = pr->bins;
   const bool has2 = pr->subs_cdf2 != nullptr;
 
-  std::vector<uint32_t> tab;
-  // substitution rows
-  const size_t sub_rows = (size_t)kmer_count * bins;
-  const size_t sub_off = 0;
-  tab.resize((has2 ? 2 : 1) * sub_rows * 4);
-  for (int t = 0; t < (has2 ? 2 : 1); t++) {
-    const double* src = t == 0 ? pr->subs_cdf1 : pr->subs_cdf2;
-    for (size_t r = 0; r < sub_rows; r++) sg::encode_sub_row(src + r * 4, &tab[(t * sub_rows + r) * 4]);
-  }
-  // quality rows, compacted to the symbols that carry probability mass (XTen: 7 of 94)
-  const size_t qrows = (size_t)16 * bins;
-  std::vector<sg::CompactRow> qr(qrows);
-  uint32_t wmax = 4;
-  for (size_t r = 0; r < qrows; r++) {
-    qr[r] = sg::encode_compact_row(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
-    if (qr[r].T.size() > wmax) wmax = (uint32_t)qr[r].T.size();
-  }
-  // odd row stride: consecutive rows start on different LDS banks (an even stride of 10 words put
-  // every first probe on 16 of the 32 banks: 62 % of LDS cycles were conflicts)
-  const uint32_t qW = (wmax + 3u) & ~3u, qstride = (qW + qW / 4) | 1u;  // width: multiple of 4, not a power of two
-  const size_t qual_off = tab.size();
-  tab.resize(qual_off + qrows * qstride, 0xFFFFFFFFu);
-  for (size_t r = 0; r < qrows; r++) {
-    uint32_t* row = &tab[qual_off + r * qstride];
-    const sg::CompactRow& cr = qr[r];
-    for (size_t i = 0; i < cr.T.size(); i++) row[i] = cr.T[i];
-    for (uint32_t i = 0; i < qW; i++) {
-      const uint32_t sym = cr.sym[i < cr.sym.size() ? i : cr.sym.size() - 1];
-      uint32_t& w = row[qW + i / 4];
-      w = (w & ~(0xFFu << (8 * (i % 4)))) | (sym << (8 * (i % 4)));
+  // context -> index of its last base (the reference base a substitution row is about): contexts with m real bases are
+  // numbered in base-4 counting order (Profile::initKmers, Profile.cpp:70-124), so the last base is the lowest digit
+  std::vector<uint8_t> ctx_cd((size_t)kmer_count);
+  {
+    int off = 0, p4 = 1;
+    for (int m = 1; m <= pr->kmer; m++) {
+      p4 *= 4;
+      for (int v = 0; v < p4; v++) ctx_cd[off + v] = (uint8_t)(v & 3);
+      off += p4;
     }
   }
+  std::vector<uint32_t> tab;
+  // substitution rows, identity first (sg_tables.h): {D0, D1, D2, j0 | o0<<2 | o1<<4 | o2<<6 | o3<<8}, o in profile codes
+  const size_t sub_rows = (size_t)kmer_count * bins;
+  const size_t sub_off = 0;
+  const int n_mates = has2 ? 2 : 1;
+  std::vector<sg::SubRow> srows((size_t)n_mates * sub_rows);
+  tab.resize((size_t)n_mates * sub_rows * 4);
+  for (int t = 0; t < n_mates; t++) {
+    const double* src = t == 0 ? pr->subs_cdf1 : pr->subs_cdf2;
+    for (size_t r = 0; r < sub_rows; r++) {
+      const sg::SubRow sr = sg::encode_sub_row_identity_first(src + r * 4, ctx_cd[r / bins]);
+      srows[t * sub_rows + r] = sr;
+      uint32_t* o = &tab[(t * sub_rows + r) * 4];
+      o[0] = sr.D[0]; o[1] = sr.D[1]; o[2] = sr.D[2];
+      o[3] = sr.j0 | (uint32_t)sr.order[0] << 2 | (uint32_t)sr.order[1] << 4 | (uint32_t)sr.order[2] << 6 | (uint32_t)sr.order[3] << 8;
+    }
+  }
+  // quality rows as alias columns (sg_tables.h): [16][bins][W] x {thr, lo | hi << 8}
+  const size_t qrows = (size_t)16 * bins;
+  std::vector<std::vector<uint64_t>> qmass(qrows);
+  uint32_t most = 1;
+  for (size_t r = 0; r < qrows; r++) {
+    qmass[r] = sg::row_masses(pr->qual_cdf + r * pr->n_qual, pr->n_qual);
+    most = std::max(most, sg::symbols_with_mass(qmass[r]));
+  }
+  uint32_t lgW = 2;
+  while ((1u << lgW) < most) lgW++;
+  const uint32_t W = 1u << lgW;
+  std::vector<sg::AliasRow> arows(qrows);
+  try {
+    for (size_t r = 0; r < qrows; r++) arows[r] = sg::build_alias_row(qmass[r], lgW);
+  } catch (const std::exception& e) {
+    return ctx->fail(SG_ERR_INVALID, std::string("sg_load_profile: ") + e.what());
+  }
+  while (tab.size() % 4) tab.push_back(0);
+  const size_t alias_off = tab.size();
+  tab.resize(alias_off + qrows * W * 2);
+  for (size_t r = 0; r < qrows; r++)
+    for (uint32_t c = 0; c < W; c++) {
+      tab[alias_off + (r * W + c) * 2] = arows[r].thr[c];
+      tab[alias_off + (r * W + c) * 2 + 1] = (uint32_t)arows[r].lo[c] | (uint32_t)arows[r].hi[c] << 8;
+    }
   auto add_row = [&](const double* cdf, int n, size_t& off, uint32_t& lg) {
     sg::Row r = sg::encode_row(cdf, n);
     uint32_t W = sg::pow2_at_least((uint32_t)r.T.size());
@@ -295,27 +337,80 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   add_row(pr->del_cdf, pr->n_del, del_off, del_lg);
   const bool has_isz = pr->isize_cdf != nullptr && pr->n_isize > 0;
   if (has_isz) add_row(pr->isize_cdf, pr->n_isize, isz_off, isz_lg);
-  // Fast-kernel context permutation.  The kernel packs base codes 2 bits each in NATURAL order
-  // (A0 C1 T2 G3) with the OLDEST base of a context in the lowest digit; the reference numbers a
-  // context with its oldest base in the highest digit, in `bases` order (Profile::initKmers).
-  const size_t perm_off = tab.size();
+  // Straight-line kernel tables (kmer 3).  The kernel packs base codes 2 bits each in NATURAL order (A0 C1 T2 G3) with
+  // the OLDEST base of a context in the lowest digit; the reference numbers a context with its oldest base in the
+  // highest digit, in `bases` order (Profile::initKmers).  Context ids of the kernel: [0,4) one base, [4,20) two, [20,84)
+  // three.  Everything below is indexed by the kernel's ids and natural base codes.
   uint32_t inv_remap = 0;
   for (int n = 0; n < 4; n++) inv_remap |= (uint32_t)n << (2 * ((remap >> (2 * n)) & 3u));
-  {
+  size_t fast_lds_off = 0, fast_sub_off = 0, fast_alias_off = 0;
+  uint32_t fast_stride = 0;
+  if (pr->kmer == 3) {
+    std::vector<uint32_t> perm;  // kernel context id -> reference context id
     uint32_t off = 0, p4 = 1;
-    for (int m = 1; m <= pr->kmer; m++) {
+    for (int m = 1; m <= 3; m++) {
       p4 *= 4;
       for (uint32_t v = 0; v < p4; v++) {
         uint32_t src = 0;
         for (int tt = 0; tt < m; tt++) {
-          const uint32_t nat = (v >> (2 * tt)) & 3u;            // base at age position tt (0 = oldest)
-          const uint32_t prof = (remap >> (2 * nat)) & 3u;
-          src |= prof << (2 * (m - 1 - tt));
+          const uint32_t nat = (v >> (2 * tt)) & 3u;  // base at age position tt (0 = oldest)
+          src |= ((remap >> (2 * nat)) & 3u) << (2 * (m - 1 - tt));
         }
-        tab.push_back(off + src);
+        perm.push_back(off + src);
       }
       off += p4;
     }
+    auto nat_of = [&](uint32_t prof) { return (inv_remap >> (2u * prof)) & 3u; };
+    auto prof_of = [&](uint32_t nat) { return (remap >> (2u * nat)) & 3u; };
+    // kernel context ids: [0,4) one base, [4,20) two, [20,84) three, the oldest base in the lowest digit.  Per bin the
+    // tables hold 192 context rows addressed by the 6-bit field kv = b[i-2] | b[i-1] << 2 | b[i] << 4 of the packed
+    // codes: [0,64) the three-base contexts, [64,128) the two-base contexts (kv >> 2; a read's second base) and
+    // [128,192) the one-base contexts (kv >> 4; a read's first base), so that every position uses the same extract.
+    auto ctx_of = [&](uint32_t slot) -> uint32_t {
+      const uint32_t kv = slot & 63u;
+      return slot < 64u ? perm[20u + kv] : slot < 128u ? perm[4u + (kv >> 2)] : perm[kv >> 4];
+    };
+    fast_stride = 192u + 4u * W;
+    while (tab.size() % 4) tab.push_back(0);
+    // (1) the LDS image, per mate and bin: [0,192) keep_h - 1 of the context's row, keep_h = c0 >> 16 (a 16-bit head
+    //     below keep_h is certainly "no substitution"); [192, 192 + 4W) the diagonal alias columns (reference base ==
+    //     called base) in the order [col][natural base] as  col << (16 - lgW) | thr >> 16  in the low half (the draw's
+    //     low half minus it is u_head - thr_head: the column bits cancel),  (lo ^ hi) << 16 | hi << 24  above
+    fast_lds_off = tab.size();
+    tab.resize(fast_lds_off + (size_t)n_mates * bins * fast_stride);
+    for (int t = 0; t < n_mates; t++)
+      for (int b = 0; b < bins; b++) {
+        uint32_t* blk = &tab[fast_lds_off + ((size_t)t * bins + b) * fast_stride];
+        for (uint32_t sl = 0; sl < 192; sl++) blk[sl] = (uint32_t)(srows[t * sub_rows + (size_t)ctx_of(sl) * bins + b].c[0] >> 16) - 1u;
+        for (uint32_t cdn = 0; cdn < 4; cdn++) {
+          const uint32_t pc = prof_of(cdn);
+          const sg::AliasRow& ar = arows[((size_t)pc * 4 + pc) * bins + b];
+          for (uint32_t c = 0; c < W; c++)
+            blk[192 + c * 4 + cdn] = (c << (16 - lgW)) | (ar.thr[c] >> 16) | (uint32_t)(ar.lo[c] ^ ar.hi[c]) << 16 | (uint32_t)ar.hi[c] << 24;
+        }
+      }
+    // (2) full substitution rows for the kernel's fix-up path: [mate][bin][192] x {D0, D1, D2, j0 | n0<<2 | .. | n3<<8}
+    while (tab.size() % 4) tab.push_back(0);
+    fast_sub_off = tab.size();
+    tab.resize(fast_sub_off + (size_t)n_mates * bins * 192 * 4);
+    for (int t = 0; t < n_mates; t++)
+      for (int b = 0; b < bins; b++)
+        for (uint32_t sl = 0; sl < 192; sl++) {
+          const sg::SubRow& sr = srows[t * sub_rows + (size_t)ctx_of(sl) * bins + b];
+          uint32_t* o = &tab[fast_sub_off + (((size_t)t * bins + b) * 192 + sl) * 4];
+          o[0] = sr.D[0]; o[1] = sr.D[1]; o[2] = sr.D[2];
+          o[3] = sr.j0 | nat_of(sr.order[0]) << 2 | nat_of(sr.order[1]) << 4 | nat_of(sr.order[2]) << 6 | nat_of(sr.order[3]) << 8;
+        }
+    // (3) all alias columns in natural order: [cdn][kn][bins][W] x {thr, lo | hi << 8}
+    fast_alias_off = tab.size();
+    tab.resize(fast_alias_off + qrows * W * 2);
+    for (uint32_t cdn = 0; cdn < 4; cdn++)
+      for (uint32_t kn = 0; kn < 4; kn++)
+        for (int b = 0; b < bins; b++) {
+          const sg::AliasRow& ar = arows[((size_t)prof_of(cdn) * 4 + prof_of(kn)) * bins + b];
+          uint32_t* o = &tab[fast_alias_off + ((((size_t)cdn * 4 + kn) * bins + b) * W) * 2];
+          for (uint32_t c = 0; c < W; c++) { o[2 * c] = ar.thr[c]; o[2 * c + 1] = (uint32_t)ar.lo[c] | (uint32_t)ar.hi[c] << 8; }
+        }
     while (tab.size() % 4) tab.push_back(0);
   }
 
@@ -327,14 +422,16 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   const uint32_t* base = ctx->tab.as<uint32_t>();
   P.sub = (const uint4*)(base + sub_off);
   P.sub_mate_rows = has2 ? (uint32_t)sub_rows : 0u;
-  P.qual = base + qual_off;
-  P.qual_stride = qstride;
-  P.qual_lg = sg::log2u(sg::pow2_at_least(qW));
-  P.qual_w = qW;
+  P.alias = (const uint2*)(base + alias_off);
+  P.lgW = lgW;
+  P.fast_lds = pr->kmer == 3 ? base + fast_lds_off : nullptr;
+  P.fast_mate_words = has2 ? (uint32_t)bins * fast_stride : 0u;
+  P.fast_stride = fast_stride;
+  P.fast_sub = pr->kmer == 3 ? (const uint4*)(base + fast_sub_off) : nullptr;
+  P.fast_alias = pr->kmer == 3 ? (const uint2*)(base + fast_alias_off) : nullptr;
   P.ins_row = base + ins_off; P.ins_lg = ins_lg;
   P.del_row = base + del_off; P.del_lg = del_lg;
   P.isz_row = has_isz ? base + isz_off : nullptr; P.isz_lg = isz_lg;
-  P.sub_perm = base + perm_off;
   P.inv_remap_packed = inv_remap;
   P.isz_min = pr->isize_min;
   P.fixed_isz = pr->insert_size;
@@ -834,7 +931,9 @@ static int run_pass(sg_ctx* ctx) {
   sg::DevBatch& B = ctx->B;
   B.k0 = (uint32_t)ctx->seed;
   B.k1 = (uint32_t)(ctx->seed >> 32);
+  // timing ablations (outputs are wrong when set): SG_DIAG selects the generic emit kernel, SG_FDIAG keeps the straight-line one
   { const char* dg = getenv("SG_DIAG"); B.diag = dg ? (uint32_t)atoi(dg) : 0u; }
+  if (const char* fd = getenv("SG_FDIAG")) B.diag = (uint32_t)atoi(fd);
   hipStream_t s = ctx->stream;
   const bool prof = ctx->profiling;
   SG_HIP(hipMemsetAsync(B.totals, 0, 8 * 8, s));

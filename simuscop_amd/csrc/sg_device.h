@@ -22,10 +22,18 @@ struct PairRec {
 __host__ __device__ inline uint32_t ev_pack(uint32_t j, uint32_t len, uint32_t del) { return j | (len << 16) | (del << 31); }
 
 struct DevProfile {
-  const uint4* sub;            // [mate][kmer_count][bins] rows {T0,T1,T2,k0}
+  // Per-base sampling tables (sg_tables.h): each outcome owns exactly the draws the reference's
+  // `r <= cdf[k]` scan gives it; substitution rows are ordered identity first, quality rows are alias columns.
+  const uint4* sub;            // [mate][kmer_count][bins] rows {D0, D1, D2, j0 | o0<<2 | o1<<4 | o2<<6 | o3<<8}: j = max(j0, #{x > D_i}), k = o_j
   uint32_t sub_mate_rows;      // rows per mate table (0 when mate 2 shares mate 1's table)
-  const uint32_t* qual;        // [16][bins] rows of qual_stride words: {T0..T(W-1), sym bytes packed 4 per word}
-  uint32_t qual_stride, qual_lg, qual_w;  // W = qual_w (multiple of 4), qual_lg = ceil(log2 W) search steps
+  const uint2* alias;          // [16][bins][W] columns {thr, lo | hi << 8}: symbol = u < thr ? lo : hi
+  uint32_t lgW;                // W = 2^lgW columns (4..128)
+  // straight-line kernel (kmer 3), indexed by its own context ids and natural base codes
+  const uint32_t* fast_lds;    // [mate][bins][fast_stride]: [0,192) keep_h - 1 by context slot, then [cdn][W] diagonal alias columns (head form)
+  uint32_t fast_mate_words;    // words per mate image (0 when mate 2 shares mate 1's)
+  uint32_t fast_stride;        // 192 + 4 W
+  const uint4* fast_sub;       // [mate][bins][192] full rows, outcomes as natural codes
+  const uint2* fast_alias;     // [cdn][kn][bins][W] full columns
   const uint32_t* ins_row; uint32_t ins_lg;
   const uint32_t* del_row; uint32_t del_lg;
   const uint32_t* isz_row; uint32_t isz_lg;  // isz_row == nullptr -> fixed insert size
@@ -37,7 +45,6 @@ struct DevProfile {
   uint32_t remap_packed;       // natural index (A0 C1 T2 G3) -> profile base code, 2 bits each
   uint32_t bases_packed;       // profile base code -> ASCII, 8 bits each
   uint32_t kmer_off[8];        // kmer_off[m] = first table index of contexts with m real bases
-  const uint32_t* sub_perm;    // fast kernel: context id in packed-natural digit order -> reference context id
   uint32_t inv_remap_packed;   // profile base code -> natural index (A0 C1 T2 G3), 2 bits each
 };
 

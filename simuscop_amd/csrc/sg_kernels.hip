@@ -56,17 +56,6 @@ __device__ __forceinline__ uint32_t row_search(const uint32_t* __restrict__ row,
   return row[0] + pos;
 }
 
-// quality row {T0..T(W-1), sym bytes}: symbol of the first threshold >= x.  W is a multiple of 4 but
-// not necessarily a power of two: probes past the row count as +infinity.
-__device__ __forceinline__ uint32_t qual_lookup(const uint32_t* __restrict__ row, uint32_t w, uint32_t lg, uint32_t x) {
-  uint32_t pos = 0;
-  for (uint32_t step = lg ? (1u << (lg - 1)) : 0; step; step >>= 1) {
-    const uint32_t i = pos + step - 1;
-    if (i < w && x > row[i]) pos += step;
-  }
-  return ((const uint8_t*)(row + w))[pos];
-}
-
 __device__ __forceinline__ uint32_t aux_draw(const DevBatch& B, uint32_t slot, uint32_t j, uint32_t f, uint32_t mate) {
   uint32_t x[4];
   philox4x32_10(slot + B.slot_offset, j, f >> 2, dev_ctx(KIND_AUX, mate, B.batch_id), B.k0, B.k1, x);
@@ -529,10 +518,9 @@ __device__ __noinline__ uint64_t slow_codes(const uint8_t* frag, uint32_t flen, 
 
 // One item = output positions [8c, 8c+8) of one read: sample and store bases + qualities.
 //   m0 = {frag_lo, frag_hi, out_lo, out_hi}   m1 = {flen | rev<<31, np | nev<<16 (6 bits) | hdr<<22, inv, -}
-template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
-__device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
-                                          const uint32_t* lds_qual, const uint4* gsub, uint32_t m, const uint4 m0,
-                                          const uint4 m1, uint32_t slot, uint32_t c, bool active) {
+template <int KT, bool SUB_LDS>
+__device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub, const uint4* gsub,
+                                          uint32_t m, const uint4 m0, const uint4 m1, uint32_t slot, uint32_t c, bool active) {
   const uint32_t K = KT ? (uint32_t)KT : (uint32_t)P.kmer;
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t ctxmask = (1u << (2 * K)) - 1u;
@@ -630,14 +618,20 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
       vc = valid ? min(vc + 1u, K) : 0u;
     }
   }
-  // ---- four Philox calls: [sub, qual] for 8 bases (counter = i/2) ----
-  uint32_t x[16];
+  // ---- four Philox calls: heads and tails of output positions i0 .. i0+7 (call = i/4, c2 = 0 heads / 1 tails, word = i%4):
+  //   substitution draw = heads[31:16] << 16 | tails[31:16],  quality draw = heads[15:0] << 16 | tails[15:0]
+  uint32_t xh[8], xt[8];
   const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
 #pragma unroll
-  for (int h = 0; h < 4; h++) {
-    if (B.diag & 8u) { for (int z = 0; z < 4; z++) x[4 * h + z] = (slot * 2654435761u) ^ (c * 40503u + (4 * h + z) * 0x9E3779B9u); }
-    else philox4x32_10(slot + B.slot_offset, 4u * c + (uint32_t)h, 0, c3b, B.k0, B.k1, x + 4 * h);
+  for (int g = 0; g < 2; g++) {
+    if (B.diag & 8u) {
+      for (int z = 0; z < 4; z++) { xh[4 * g + z] = (slot * 2654435761u) ^ (c * 40503u + (4 * g + z) * 0x9E3779B9u); xt[4 * g + z] = ~xh[4 * g + z]; }
+    } else {
+      philox4x32_10(slot + B.slot_offset, 2u * c + (uint32_t)g, 0, c3b, B.k0, B.k1, xh + 4 * g);
+      philox4x32_10(slot + B.slot_offset, 2u * c + (uint32_t)g, 1, c3b, B.k0, B.k1, xt + 4 * g);
+    }
   }
+  const uint32_t lgW = P.lgW;
   uint32_t sw[2] = {0, 0}, qw[2] = {0, 0};
 #pragma unroll
   for (int h = 0; h < 8; h++) {
@@ -646,7 +640,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     const bool valid = cd < 4u;
     ctxv = ((ctxv << 2) | (cd & 3u)) & ctxmask;
     vc = valid ? min(vc + 1u, K) : 0u;
-    const uint32_t xs = x[2 * h], xq = x[2 * h + 1];
+    const uint32_t xs = (xh[h] & 0xFFFF0000u) | (xt[h] >> 16), xq = (xh[h] << 16) | (xt[h] & 0xFFFFu);
     const uint32_t bin = min(__umulhi(i * bins, inv), bins - 1u);  // i*binCount/n' (clamp only guards idle lanes)
     const uint32_t mlen = min(i + 1u, K);
     const uint32_t mmask = (1u << (2u * mlen)) - 1u;
@@ -654,22 +648,15 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     // contexts with m real bases start at (4^m-4)/3 = (0x55555555 & (4^m-1)) - 1
     const uint32_t kidx = ctx_ok ? ((0x55555555u & mmask) - 1u) + (ctxv & mmask) : 0u;
     const uint4 row = SUB_LDS ? lds_sub[kidx * bins + bin] : gsub[(size_t)kidx * bins + bin];
-    const uint32_t cnt = (xs > row.x) + (xs > row.y) + (xs > row.z);
-    const uint32_t k = ctx_ok ? max(cnt, row.w) : cd;  // unknown context: the base is copied (Profile.cpp:1531-1533)
+    // identity-first row: j = max(j0, #{xs > D_i}), called base = o_j (o_0 = the reference base)
+    const uint32_t j = max((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z), row.w & 3u);
+    const uint32_t k = ctx_ok ? ((row.w >> (2u * j + 2u)) & 3u) : cd;  // unknown context: the base is copied (Profile.cpp:1531-1533)
     const bool kvalid = k < 4u;
     const uint32_t kk = kvalid ? k : 0u;
-    const uint32_t rowi = (((valid ? cd : 0u) * 4u + kk) * bins + bin) * P.qual_stride;
-    const uint32_t* qrow = QUAL_LDS ? lds_qual + rowi : P.qual + rowi;
-    uint32_t qi;
-    if (B.diag & 16u) qi = 7u + (xq >> 29);
-    else if (QLG == 3) {  // 8-wide row: three probes, then the symbol byte
-      uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
-      pos += (xq > qrow[pos + 1]) ? 2u : 0u;
-      pos += (xq > qrow[pos]) ? 1u : 0u;
-      qi = (qrow[8 + (pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-    } else {
-      qi = qual_lookup(qrow, P.qual_w, P.qual_lg, xq);
-    }
+    // alias column of row (reference base, called base, bin)
+    const uint2 e = P.alias[(((size_t)((valid ? cd : 0u) * 4u + kk) * bins + bin) << lgW) + (xq >> (32u - lgW))];
+    const uint32_t u = xq & ((1u << (32u - lgW)) - 1u);
+    const uint32_t qi = (B.diag & 16u) ? 7u + (xq >> 29) : (u < e.x ? (e.y & 0xFFu) : ((e.y >> 8) & 0xFFu));
     uint32_t ch = kvalid ? ((P.bases_packed >> (8u * kk)) & 0xFFu) : (uint32_t)'N';
     uint32_t q = (uint32_t)P.min_qual + (kvalid ? qi : __umulhi(xq, 20u));  // getRandBaseQuality, Profile.cpp:1582-1584
     if (i >= np) {  // "\n+\n" after the bases, '\n' after the qualities
@@ -691,22 +678,18 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   }
 }
 
-template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
-__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
-                                                            uint32_t TI, uint32_t RPI) {
+template <int KT, bool SUB_LDS>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t TI, uint32_t RPI) {
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
   const uint32_t tm = B.paired ? m : 0u;  // SE always samples from the mate-1 tables (Segment.cpp:770,777)
-  // ---- LDS carve-up: [sub rows][qual words][per-wave metadata rows] ----
+  // ---- LDS carve-up: [sub rows][per-wave metadata rows]; the alias columns are read through L2 ----
   uint4* lds_sub = smem;
-  uint32_t* lds_qual = (uint32_t*)(smem + (SUB_LDS ? sub_rows : 0u));
-  uint4* lds_meta_all = (uint4*)(lds_qual + (QUAL_LDS ? ((qual_words + 3u) & ~3u) : 0u));
+  uint4* lds_meta_all = smem + (SUB_LDS ? sub_rows : 0u);
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   if (SUB_LDS)
     for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) lds_sub[i] = gsub[i];
-  if (QUAL_LDS)
-    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) lds_qual[i] = P.qual[i];
   __syncthreads();
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
 
@@ -765,7 +748,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
           if (cb >= nitems) { more &= more - 1ull; cb = TI; }
         }
         const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
-        emit_item<KT, QLG, SUB_LDS, QUAL_LDS>(P, B, lds_sub, lds_qual, gsub, m, m0, m1, g * G + r, active ? c : 0u, active);
+        emit_item<KT, SUB_LDS>(P, B, lds_sub, gsub, m, m0, m1, g * G + r, active ? c : 0u, active);
       }
     }
 
@@ -777,53 +760,85 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
 }
 
 // ------------------------------------------------------------------------------------------------
-// emit, straight-line variant for the common profile shape: kmer == 3, tables in LDS (quality rows of
-// <= 8 symbols whole, wider alphabets with the reference == called rows only: DIAG).  Same results as
-// emit_kernel, far fewer instructions:
-//   * the 13 source codes of an item are packed 2 bits each (natural order A0 C1 T2 G3) into one
-//     word, so a k-mer context is ONE bit-field extract; the LDS copy of the substitution table is
-//     permuted at staging time to that digit order (DevProfile::sub_perm), the quality rows to the
-//     natural reference-base order;
-//   * the 8-base block is straight-line and branch-free (the compiler can overlap the LDS reads of
-//     different bases); first-of-read contexts ("XXb", "Xbb") use per-lane extract constants;
+// emit, straight-line variant for the common profile shape (kmer == 3, tables in LDS).  Same results as
+// emit_kernel, far fewer instructions.  Cost model (tools/valu_microbench.hip, 4 waves per SIMD): only
+// add / sub / and / or / xor / right shift / mov issue at 2.3 cycles per wave instruction (v_bitop3_b32 2.8);
+// compares, selects, left shifts, bit-field extracts, multiplies and every other three-operand integer op take
+// 4.2.  The 8-base block is therefore written in subtractions, right shifts and three-input boolean ops:
+//   * the 13 source codes of an item are packed 2 bits each (natural order A0 C1 T2 G3) into one word, so a
+//     k-mer context is a shift and a mask; the tables are laid out for that digit order on the host;
+//   * per base ONE 32-bit draw (the "heads" word): 12 bits decide "no substitution" against the context row's
+//     keep count (identity-first rows: one subtraction, the sign is the answer), 20 bits pick an alias column of
+//     the (reference == called) quality row and the side of its threshold (again a subtraction; the sign,
+//     extended over the high bits, selects the symbol through a three-input boolean op);
+//   * a base the heads cannot decide -- a substitution (0.35 % of the bases), a head equal to a threshold's --
+//     sets a flag bit; flagged bases are redone exactly by the fix-up loop after the block (full rows from L2,
+//     the "tails" Philox call only for a head on a threshold);
+//   * table addresses come from a per-item look-up row (bin offsets of the item's eight positions; the short
+//     contexts of a read's first two bases are table regions of their own, selected by that row);
 //   * a group's reads walk the steps as one item stream, 64 items per step, ordered by event class;
 //   * what is per read rather than per item -- header text, the partial last item, "\n+\n" and '\n' --
 //     is stored by a per-read pass once per group (the last item waits in the read's own LDS row);
-//   * windows holding a non-ACGT base and reads with >= 2 sequencing indels (both rare; DIAG: items
-//     with a substitution) go to a global queue for emit_slow_kernel.
+//   * windows holding a non-ACGT base and items two sequencing indels reach into (both rare) go to a global
+//     queue for emit_slow_kernel.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..3) -> 8 bits
   return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
 }
 
-template <bool PAIRED, bool DIAG, bool GUARD>
-__device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint4* lds_sub,
-                                          const uint32_t* lds_qual, uint32_t m, const uint4 m0, const uint4 m1,
-                                          uint32_t slot, uint32_t c, bool active, uint32_t hoff0, uint32_t hw0,
-                                          uint32_t hk0, uint32_t hoff1, uint32_t hw1, uint32_t hk1, uint4* tail_row, int d0, uint32_t n_in,
-                                          uint32_t ew_in, uint32_t tj_in) {
+#define FAST_CTX 192u  // context rows per bin: [0,64) three bases, [64,128) two bases (x4), [128,192) one base (x16)
+#define LUT_ROW 12u    // dwords per item in the look-up row: so[0..7], qo[0..1], 2 unused
+
+// v_bitop3_b32 truth tables, f(a, b, c) evaluated on a = 0xF0, b = 0xCC, c = 0xAA
+#define BITOP_OR_AND 0xF8       // a | (b & c)
+#define BITOP_XOR_AND 0x78      // a ^ (b & c)
+#define BITOP_ANDN_OR 0xBA      // (a & ~b) | c
+
+// "tails" word of output position i0 + h (KIND_BASE call (2c + h/4, 1)); rare, kept out of line
+__device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h, uint32_t c3b, uint32_t k0, uint32_t k1) {
+  uint32_t y[4];
+  philox4x32_10(slot, 2u * c + (h >> 2), 1u, c3b, k0, k1, y);
+  const uint32_t l = h & 3u;
+  return l == 0u ? y[0] : l == 1u ? y[1] : l == 2u ? y[2] : y[3];
+}
+
+// Address of an item's un-shifted template window: 16 encoded haplotype bytes such that, after the byte reversal of
+// reverse reads, output position p sits at byte p - 8c + 5.  Idle lanes read a harmless in-bounds address.
+template <bool PAIRED>
+__device__ __forceinline__ const uint8_t* fast_src(const DevBatch& B, uint32_t m, const uint4 m0, const uint4 m1, uint32_t c, bool active) {
+  const uint32_t flen = m1.x & 0x7FFFFFFFu;
+  const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
+  const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
+  const int i0 = (int)(8u * c);
+  return !active ? B.chains + 128 : (rev ? frag + (int)flen - i0 - 11 : frag + i0 - 5);
+}
+
+template <bool PAIRED>
+__device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint32_t* img, const uint32_t* lut,
+                                          const uint32_t* code4, uint32_t TI, uint32_t m, const uint4 m0, const uint4 m1,
+                                          uint32_t slot, uint32_t c, bool active, uint4* tail_row, int d0, uint32_t n_in,
+                                          uint32_t ew_in, uint32_t tj_in, const uint8_t* src0, uint4 wpre, uint32_t& fix,
+                                          uint32_t& cw_out) {
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
-  // GUARD (item-stream map): an idle lane may be looking at a row whose read is finished; its fragment
-  // offset, reciprocal and event word then hold the parked last item (see below), so an idle lane must
-  // not follow them -- it reads a harmless in-bounds window and has no event.  With the fixed map an
-  // idle lane only ever sees rows of reads of its own step, which are still intact when it loads them.
-  // The caller has reduced the read's sequencing indels to what this item sees: d0 = template index minus
-  // output index at the item's first position (events before it), n_in = events reaching into it (0, 1,
-  // or 2 = too many for the two-window code), ew_in = that event with its OUTPUT position, tj_in = its
+  // An idle lane may be looking at a row whose read is finished; its fragment offset, reciprocal and event word then
+  // hold the parked last item (see below), so an idle lane must not follow them -- it reads a harmless in-bounds
+  // window and has no event.  The caller has reduced the read's sequencing indels to what this item sees: d0 =
+  // template index minus output index at the item's first position (events before it), n_in = events reaching into
+  // it (0, 1, or 2 = too many for the two-window code), ew_in = that event with its OUTPUT position, tj_in = its
   // template position (the address of its draws).
-  const uint32_t np = m1.y & 0xFFFFu, nev = (GUARD && !active) ? 0u : n_in, hdr = m1.y >> 22;
+  const uint32_t np = m1.y & 0xFFFFu, nev = active ? n_in : 0u, hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
-  const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
-  const bool no_frag = GUARD ? !active : flen == 0u;
-  const uint8_t* src = no_frag ? B.chains + 128 : (rev ? frag + (int)flen - (int)i0 - 11 - d0 : frag + (int)i0 - 5 + d0);
+  // src0 = the item's un-shifted template window (fast_src), already loaded into wpre by the caller one step ahead;
+  // events before the item shift it by d0
+  const uint8_t* src = rev ? src0 - d0 : src0 + d0;
+  (void)flen;
 
   // 16 encoded bytes -> byte order by position (reverse reads), complement, validity, 2-bit pack
-  auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
-    uint32_t w[4];
-    __builtin_memcpy(w, p16, 16);
+  auto pack_window = [&](uint4 v, uint32_t& bad) -> uint32_t {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
     if (rev) {  // PAIRED: wave-uniform branch
       const uint32_t t0 = __builtin_bswap32(w[3]) ^ 0x02020202u, t1 = __builtin_bswap32(w[2]) ^ 0x02020202u;
       const uint32_t t2 = __builtin_bswap32(w[1]) ^ 0x02020202u, t3 = __builtin_bswap32(w[0]) ^ 0x02020202u;
@@ -833,8 +848,18 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     bad = (w[0] & 0xFC000000u) | ((w[1] | w[2]) & 0xFCFCFCFCu) | (w[3] & 0xFCu);
     return pack4(w[0]) | (pack4(w[1]) << 8) | (pack4(w[2]) << 16) | ((w[3] & 3u) << 24);
   };
+  auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
+    uint4 v;
+    __builtin_memcpy(&v, p16, 16);
+    return pack_window(v, bad);
+  };
+  if (__ballot(d0 != 0) != 0ull) {
+    if (d0 != 0) __builtin_memcpy(&wpre, src, 16);
+  }
   uint32_t bad;
-  uint32_t cw = window(src, bad);
+  uint32_t cw;
+  if (B.diag & 4u) { cw = slot * 2654435761u + c; bad = 0; }  // ablation: no haplotype fetch
+  else cw = pack_window(wpre, bad);
 
   // reads with exactly one sequencing indel: past the event the window is shifted by +-len
   if (__ballot(nev == 1u) != 0ull) {
@@ -867,70 +892,80 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
       }
     }
   }
-  // ---- four Philox calls: [sub, qual] for 8 bases (counter = i/2) ----
-  uint32_t x[16];
+  // ---- two Philox calls: the heads words of the item's eight positions (call = i/4, word = i%4) ----
+  uint32_t x[8];
   const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+  if (B.diag & 8u) {  // ablation: no Philox
 #pragma unroll
-  for (int h = 0; h < 4; h++) philox4x32_10(slot + B.slot_offset, 4u * c + (uint32_t)h, 0, c3b, B.k0, B.k1, x + 4 * h);
+    for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
+  } else {
+    philox4x32_10(slot + B.slot_offset, 2u * c, 0, c3b, B.k0, B.k1, x);
+    philox4x32_10(slot + B.slot_offset, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+  }
 
-  uint32_t ksel[2] = {0, 0}, qw[2] = {0, 0};
-  const uint32_t ib0 = __umul24(i0, bins);
-  uint32_t offdiag = 0;
-  const uint32_t* qrows[8];
+  // ---- table offsets of the eight positions: bin * block bytes (+ the short-context region of a read's first two
+  // bases).  Reads of the profile's own length take them from the item's look-up row; reads that a sequencing indel
+  // changed (their bins are i * binCount / n') and items past the row compute them. ----
+  const uint32_t lgW = P.lgW, blk_bytes = P.fast_stride * 4u;
+  uint32_t so[8], qo0, qo1;
+  const bool lut_ok = np == (uint32_t)P.L && c < TI;
+  if (__ballot(active && !lut_ok) == 0ull) {
+    const uint4* row = (const uint4*)(lut + (lut_ok ? c : 0u) * LUT_ROW);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+    so[0] = r0.x; so[1] = r0.y; so[2] = r0.z; so[3] = r0.w; so[4] = r1.x; so[5] = r1.y; so[6] = r1.z; so[7] = r1.w;
+    qo0 = r2.x; qo1 = r2.y;
+  } else {
+    const uint32_t ib0 = __umul24(i0, bins);
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+      // idle lanes may compute a bin past the table: LDS reads beyond the allocation return 0, results unused
+      const uint32_t bin = __umulhi(ib0 + (uint32_t)h * bins, inv);
+      so[h] = __umul24(active ? bin : 0u, blk_bytes);
+    }
+    qo0 = so[0]; qo1 = so[1];
+    if (c == 0u) { so[0] += 128u * 4u; so[1] += 64u * 4u; }
+  }
+  // ---- the 8-base block.  Every VALU instruction costs about the same here (~4.2 cycles in this mix), so the block is
+  // written for few instructions: 16-bit fields that operand selects (SDWA) pick for free, byte permutes for packing. ----
+  const uint8_t* img_b = (const uint8_t*)img;
+  // the items's eight reference codes as bytes code * 4 (alias column offset, and >> 2 the character selector)
+  const uint32_t cd4[2] = {code4[(cw >> 10) & 0xFFu], code4[(cw >> 18) & 0xFFu]};
+  const uint32_t col_at = 16u - lgW;
+  uint32_t acc = 0, sy[8];
 #pragma unroll
   for (int h = 0; h < 8; h++) {
-    const uint32_t xs = x[2 * h];
-    // context id in packed digit order; first two bases of a read use the short-context blocks
-    uint32_t kv;
-    if (h == 0) kv = __builtin_amdgcn_ubfe(cw, hoff0, hw0) + hk0;
-    else if (h == 1) kv = __builtin_amdgcn_ubfe(cw, hoff1, hw1) + hk1;
-    else kv = ((cw >> (2 * h + 6)) & 63u) + 20u;
-    // i*binCount/n'.  Idle lanes may compute a bin past the table: LDS reads beyond the allocation
-    // return 0 and their results are never stored.
-    const uint32_t bin = __umulhi(ib0 + (uint32_t)h * bins, inv);
-    const uint4 row = lds_sub[__umul24(kv, bins) + bin];
-    const uint32_t k = max((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z), row.w);
-    const uint32_t cd = (cw >> (2 * h + 10)) & 3u;
-    ksel[h >> 2] |= k << (8 * (h & 3));
-    if (DIAG) {
-      // only the (reference base == called base) quality rows live in LDS; an item with a substitution
-      // is finished by the generic code
-      offdiag |= k ^ ((P.remap_packed >> (2u * cd)) & 3u);
-      qrows[h] = lds_qual + __umul24(__umul24(cd, bins) + bin, P.qual_stride);
-    } else {
-      qrows[h] = lds_qual + __umul24(__umul24((cd << 2) | k, bins) + bin, P.qual_stride);
-    }
+    const uint32_t wh = x[h];
+    // substitution: sure "none" iff the 16-bit head (high half) is below the row's keep count: d_s = keep_h - 1 - head >= 0
+    const uint32_t kv = __builtin_amdgcn_ubfe(cw, 2 * h + 6, 6);
+    const uint32_t keepm1 = *(const uint32_t*)(img_b + so[h] + (kv << 2));
+    const uint32_t d_s = keepm1 - (wh >> 16);
+    // quality: alias column (col, cd) of the diagonal row; its low half holds col : thr_head, so the draw's low half minus
+    // it is d_q = u_head - thr_head: negative -> lo, positive -> hi, zero -> the tail decides (fix-up)
+    const uint32_t col = __builtin_amdgcn_ubfe(wh, col_at, lgW);
+    const uint32_t qa = (h == 0 ? qo0 : h == 1 ? qo1 : so[h]) + ((cd4[h >> 2] >> (8 * (h & 3))) & 0xFFu);
+    const uint32_t e = *(const uint32_t*)(img_b + qa + (col << 4) + FAST_CTX * 4u);
+    const uint32_t d_q = (wh & 0xFFFFu) - (e & 0xFFFFu);
+    // flag (bits 17.. are copies of it): substitution possible (d_s < 0) or head on the threshold (d_q == 0)
+    const uint32_t z = __builtin_amdgcn_bitop3_b32(d_q - 1u, d_q, d_s, BITOP_ANDN_OR);
+    acc = __builtin_amdgcn_bitop3_b32(acc, z, 1u << (17 + h), BITOP_OR_AND);
+    // symbol = hi ^ ((lo ^ hi) & (d_q < 0)), fields at bits 24.. and 16..: lands in byte 2
+    sy[h] = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
   }
-  if (!DIAG) {
+  // byte 2 of four symbols words -> one word (selector bytes: 0-3 from the second operand, 4-7 from the first)
+  uint32_t qw[2], sw[2];
 #pragma unroll
-    for (int h = 0; h < 8; h++) {  // 8-wide rows: three probes, then the symbol byte
-      const uint32_t xq = x[2 * h + 1];
-      const uint32_t* qrow = qrows[h];
-      uint32_t pos = (xq > qrow[3]) ? 4u : 0u;
-      pos += (xq > qrow[pos + 1]) ? 2u : 0u;
-      pos += (xq > qrow[pos]) ? 1u : 0u;
-      qw[h >> 2] |= (uint32_t)((const uint8_t*)(qrow + 8))[pos] << (8 * (h & 3));
-    }
-  } else {
-    // rows of P.qual_w symbols: qual_lg probe rounds, the 8 bases' probes of a round are independent
-    uint32_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t step = 1u << (P.qual_lg - 1u); step; step >>= 1) {
-#pragma unroll
-      for (int h = 0; h < 8; h++) {
-        const uint32_t i = pos[h] + step - 1u;
-        const uint32_t t = i < P.qual_w ? qrows[h][i] : 0xFFFFFFFFu;
-        pos[h] += (x[2 * h + 1] > t) ? step : 0u;
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 8; h++) qw[h >> 2] |= (uint32_t)((const uint8_t*)(qrows[h] + P.qual_w))[pos[h]] << (8 * (h & 3));
+  for (int g = 0; g < 2; g++) {
+    const uint32_t p01 = __builtin_amdgcn_perm(sy[4 * g + 1], sy[4 * g], 0x0C0C0602u);
+    const uint32_t p23 = __builtin_amdgcn_perm(sy[4 * g + 3], sy[4 * g + 2], 0x06020C0Cu);
+    qw[g] = p01 | p23;
+    // called bases = reference bases: code -> character
+    sw[g] = __builtin_amdgcn_perm(0u, 0x47544341u, cd4[g] >> 2);  // "ACTG"
   }
-  const bool slow = active && (bad != 0u || nev >= 2u || offdiag != 0u);  // queued for the generic item code by the caller
+  const bool slow = active && (bad != 0u || nev >= 2u);  // queued for the generic item code by the caller
+  // flagged bases are redone exactly by the group's fix-up pass (the flags of a queued item do not matter)
+  fix = (active && !slow && !(B.diag & 16u)) ? (acc >> 17) & 0xFFu & ((1u << min(8u, np - i0)) - 1u) : 0u;
+  cw_out = cw;
   const bool go = active && !slow;
-  // called base characters: byte select from `bases` by the packed codes, quality symbols -> ASCII
-  uint32_t sw[2];
-  sw[0] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[0]);
-  sw[1] = __builtin_amdgcn_perm(0u, P.bases_packed, ksel[1]);
   qw[0] += 0x01010101u * (uint32_t)P.min_qual;
   qw[1] += 0x01010101u * (uint32_t)P.min_qual;
   // A whole item is two 8-byte stores.  The read's last, partial item (np % 8 bases) is parked in the
@@ -938,12 +973,12 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   // separators, so the byte-granular stores run once per read group rather than in every step.
   if (active) {
     if (i0 + 8u <= np) {
-      if (go) {
+      if (go && !(B.diag & 1u)) {
         const uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
-        uint8_t* so = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
-        uint8_t* qo = so + np + 3u;
-        __builtin_memcpy(so, &S, 8);
-        __builtin_memcpy(qo, &Q, 8);
+        uint8_t* so_ = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
+        uint8_t* qo_ = so_ + np + 3u;
+        __builtin_memcpy(so_, &S, 8);
+        __builtin_memcpy(qo_, &Q, 8);
       }
     } else {
       // parked in the read's own LDS row, over the fields no lane needs once the last item has been
@@ -966,69 +1001,63 @@ __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, 
 }
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
+#define FIX_CAP 128   // per-wave list of flagged bases waiting for the group's fix-up pass
 
-template <bool PAIRED, bool DIAG, bool STREAM>
-__global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words,
-                                                                 uint32_t TI, uint32_t map_arg) {
+template <bool PAIRED>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t TI, uint32_t inv_TI) {
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
   const uint32_t tm = PAIRED ? m : 0u;
   const uint32_t bins = (uint32_t)P.bins;
-  uint4* lds_sub = smem;
-  uint32_t* lds_qual = (uint32_t*)(smem + sub_rows);
-  uint4* lds_meta_all = (uint4*)(lds_qual + ((qual_words + 3u) & ~3u));
+  // ---- LDS: [table image: bins x fast_stride words][look-up rows: TI x 12][256 words: four 2-bit codes -> bytes code * 4]
+  //           [per-wave read rows][slow-item queues][fix-up lists][read order][appended items] ----
+  const uint32_t img_words = bins * P.fast_stride;
+  uint32_t* img = (uint32_t*)smem;
+  uint32_t* lut = img + ((img_words + 3u) & ~3u);
+  uint32_t* code4 = lut + TI * LUT_ROW;
+  uint4* lds_meta_all = (uint4*)(code4 + 256);
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
-  uint8_t* perm_all = (uint8_t*)(slow_all + EMIT_WAVES * SLOW_CAP);
+  uint2* fix_all = (uint2*)(slow_all + EMIT_WAVES * SLOW_CAP);
+  uint8_t* perm_all = (uint8_t*)(fix_all + EMIT_WAVES * FIX_CAP);
   uint16_t* ovf_all = (uint16_t*)(perm_all + EMIT_WAVES * 64);  // items just past the stream map (read | item << 8)
-  const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
-  // staging with the fast kernel's digit / base-order permutations
-  for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) {
-    const uint32_t d = i / bins, b = i - d * bins;
-    lds_sub[i] = gsub[(size_t)P.sub_perm[d] * bins + b];
-  }
-  const uint32_t qrow_words = 4u * bins * P.qual_stride;  // rows of one reference base
-  if (!DIAG) {
-    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {
-      const uint32_t cdn = i / qrow_words, rest = i - cdn * qrow_words;
-      lds_qual[i] = P.qual[((P.remap_packed >> (2u * cdn)) & 3u) * qrow_words + rest];
+  {
+    const uint4* src = (const uint4*)(P.fast_lds + (size_t)tm * P.fast_mate_words);  // 16-byte aligned on the host
+    for (uint32_t i = tid; i < (img_words + 3u) / 4u; i += EMIT_THREADS) ((uint4*)img)[i] = src[i];
+    // look-up rows for reads of the profile's own length: bin = i * binCount / L (Profile.cpp:1672)
+    const uint32_t blk_bytes = P.fast_stride * 4u;
+    for (uint32_t i = tid; i < TI * LUT_ROW; i += EMIT_THREADS) {
+      const uint32_t c = i / LUT_ROW, f = i - c * LUT_ROW;
+      const uint32_t h = f < 8u ? f : f - 8u;
+      const uint32_t pos = 8u * c + h;
+      const uint32_t bin = min(pos * bins / (uint32_t)P.L, bins - 1u);
+      uint32_t v = bin * blk_bytes;
+      if (f < 8u && c == 0u) v += f == 0u ? 128u * 4u : f == 1u ? 64u * 4u : 0u;
+      lut[i] = f < 10u ? v : 0u;
     }
-  } else {
-    // diagonal rows only: LDS row (cdn, bin) <- table row (ref = called = profile code of cdn, bin)
-    const uint32_t drow_words = bins * P.qual_stride;
-    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) {  // qual_words = 4 * drow_words here
-      const uint32_t cdn = i / drow_words, rest = i - cdn * drow_words;
-      const uint32_t pc = (P.remap_packed >> (2u * cdn)) & 3u;
-      lds_qual[i] = P.qual[pc * qrow_words + pc * drow_words + rest];
+    for (uint32_t i = tid; i < 256u; i += EMIT_THREADS) {
+      uint32_t v = 0;
+      for (uint32_t z = 0; z < 4u; z++) v |= (((i >> (2u * z)) & 3u) * 4u) << (8u * z);
+      code4[i] = v;
     }
   }
   __syncthreads();
   uint4* meta_rows = lds_meta_all + (size_t)wv * 64 * (META_ROW / 16);
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
+  uint2* fix_list = fix_all + wv * FIX_CAP;
   uint8_t* perm = perm_all + wv * 64;
   uint16_t* ovf = ovf_all + wv * 128;
 
-  // Two lane -> (read, item) maps over the first TI items of a group's reads:
-  //   STREAM  G = 63 reads; their items form one stream, 64 per step: lane l of step s does stream item
-  //           i = 64 s + l = item i % TI of the (i / TI)-th read in step order; every lane busy whatever TI is;
-  //   fixed   RPI = 64 / TI whole reads per step, lane = (read in step, item): constant per lane, cheaper per
-  //           step, but 64 - RPI * TI lanes idle (7 at TI 19).
-  // map_arg = ceil-reciprocal of TI (STREAM) or RPI (fixed).  launch_emit picks by measurement.
-  const uint32_t inv_TI = map_arg, RPI = STREAM ? 1u : map_arg;
-  // STREAM: 63 reads, so that TI steps (64 TI item slots) hold their 63 TI map items plus up to TI appended ones
-  const uint32_t G = STREAM ? 63u : RPI * (64u / RPI);
+  // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one
+  // stream, 64 per step: lane l of step s does stream item i = 64 s + l = item i % TI of the (i / TI)-th read in step
+  // order; every lane busy whatever TI is (63 reads, so that TI steps hold the 63 TI map items plus up to TI appended
+  // ones).  inv_TI = ceil-reciprocal of TI.
+  const uint32_t G = 63u;
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
-  const uint32_t sub = lane / TI, c_lane = lane - sub * TI;
-  const bool lane_ok = sub < RPI;
-  // first item of a read: its first two bases have 1- and 2-base contexts ("XXb", "Xbb")
-  const bool head_f = c_lane == 0u;
-  const uint32_t hoff0 = head_f ? 10u : 6u, hw0 = head_f ? 2u : 6u, hk0 = head_f ? 0u : 20u;
-  const uint32_t hoff1 = head_f ? 10u : 8u, hw1 = head_f ? 4u : 6u, hk1 = head_f ? 4u : 20u;
   // XCD-aware order: workgroups go to the 8 XCDs round-robin by their linear id, so the 16 workgroups of
   // one XCD (x % 8 equal; both mates) take 16 CONSECUTIVE runs of read groups each round -- neighbouring
   // reads overlap on the haplotype (30x coverage), and their lines are then fetched into one L2 instead of
-  // eight.  (Measured on C2: FETCH_SIZE and time unchanged -- the haplotype bytes were already fetched about
-  // once, the read-side traffic is the per-read rows -- so this is tidiness, not a speed-up.)
+  // eight.
   const uint32_t bx = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   // first group by position, further groups from a per-mate counter: waves that drew cheap groups (few
   // event reads) take more of them, so the grid drains evenly
@@ -1049,7 +1078,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
     wave_lds_sync();
-    uint32_t nslow = 0;  // wave-uniform
+    uint32_t nslow = 0, nfix = 0;  // wave-uniform
     // Items the straight-line code cannot do (non-ACGT window, >= 2 indels) go to the batch's global
     // queue: one atomic per flush reserves the range; emit_slow_kernel runs the generic code on them
     // afterwards.  Keeping that code out of this kernel is worth ~14 % (SGPR spills, I-cache).
@@ -1069,13 +1098,84 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       nslow = 0;
       wave_lds_sync();
     };
+    // The fix-up pass, lane = flagged base: the bases the heads could not decide (a possible substitution, a head equal
+    // to a threshold's) are sampled again exactly -- full identity-first row and alias column from L2, the tails call
+    // only when a head sits on a threshold -- and patched into the text already stored (or into the parked last item).
+    // Run once per read group (and whenever the list fills): one pass serves ~40 flagged bases, where a loop inside the
+    // step would run for one or two lanes in five steps out of six.
+    auto flush_fix = [&]() {
+      wave_lds_sync();
+      // the items' own stores must have landed before single bytes of them are rewritten
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      const uint32_t lgW = P.lgW, u_mask = (1u << (16u - lgW)) - 1u;
+      const uint4* gsub = P.fast_sub + (size_t)tm * bins * FAST_CTX;
+      const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+      for (uint32_t b0 = 0; b0 < nfix; b0 += 64u) {
+        const bool on = b0 + lane < nfix;
+        const uint2 fe = fix_list[on ? b0 + lane : 0u];
+        const uint32_t r = fe.x & 63u, h = (fe.x >> 6) & 7u, bin = (fe.x >> 9) & 0xFFu, c = fe.x >> 17, cw = fe.y;
+        const uint32_t slot = g * G + r + B.slot_offset;
+        uint32_t xw[4];
+        philox4x32_10(slot, 2u * c + (h >> 2), 0, c3b, B.k0, B.k1, xw);
+        const uint32_t l = h & 3u;
+        const uint32_t wh = l == 0u ? xw[0] : l == 1u ? xw[1] : l == 2u ? xw[2] : xw[3];
+        const uint32_t region = c == 0u ? (h == 0u ? 128u : h == 1u ? 64u : 0u) : 0u;
+        const uint32_t cdn = (cw >> (2u * h + 10u)) & 3u;
+        const uint4 row = gsub[(size_t)bin * FAST_CTX + region + ((cw >> (2u * h + 6u)) & 63u)];
+        // identity-first row on the 16-bit head: certain unless the head equals a threshold's
+        const uint32_t sh = wh >> 16, h0 = row.x >> 16, h1 = row.y >> 16, h2 = row.z >> 16;
+        const uint32_t jj = (uint32_t)(sh > h0) + (uint32_t)(sh > h1) + (uint32_t)(sh > h2);
+        const bool amb_s = on && jj != (uint32_t)(sh >= h0) + (uint32_t)(sh >= h1) + (uint32_t)(sh >= h2);
+        uint32_t kn = 0;
+        uint2 e2 = make_uint2(0, 0);
+        const uint32_t col = (wh & 0xFFFFu) >> (16u - lgW), uh = wh & u_mask;
+        auto column = [&](uint32_t j_) {
+          const uint32_t jm = max(j_, row.w & 3u);
+          kn = (row.w >> (2u * jm + 2u)) & 3u;
+          e2 = P.fast_alias[((((size_t)cdn * 4u + kn) * bins + bin) << lgW) + col];
+        };
+        if (!amb_s) column(jj);
+        const bool need_tail = amb_s || (on && uh == (e2.x >> 16) && (e2.y & 0xFFu) != (e2.y >> 8));
+        uint32_t wt = 0;
+        if (__ballot(need_tail) != 0ull) {
+          if (need_tail) wt = tail_word(slot, c, h, c3b, B.k0, B.k1);
+        }
+        if (__ballot(amb_s) != 0ull) {
+          if (amb_s) {
+            const uint32_t xs = (wh & 0xFFFF0000u) | (wt >> 16);
+            column((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z));
+          }
+        }
+        // side of the column: the head decides unless it sits on the threshold's (then the 16-bit tail does)
+        const uint32_t th = e2.x >> 16;
+        const bool lo_side = uh != th ? uh < th : ((uh << 16) | (wt & 0xFFFFu)) < e2.x;
+        const uint32_t sym = (lo_side ? (e2.y & 0xFFu) : (e2.y >> 8)) + (uint32_t)P.min_qual;
+        const uint32_t ch = (0x47544341u >> (8u * kn)) & 0xFFu;  // "ACTG"[kn]: natural code -> character
+        if (on) {
+          const uint4 r0 = meta_rows[r * 2], r1 = meta_rows[r * 2 + 1];
+          const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22, i = 8u * c + h;
+          if (8u * c + 8u <= np) {
+            uint8_t* rec = B.out[m] + (((uint64_t)r0.w << 32) | r0.z) + hl + i;
+            rec[0] = (uint8_t)ch;
+            rec[np + 3u] = (uint8_t)sym;
+          } else if (r0.x != 0xFFFFFFFFu) {
+            // the read's parked last item: characters in words 0, 1, qualities in words 6, 7 of its row
+            uint8_t* row8 = (uint8_t*)(meta_rows + r * 2);
+            row8[h] = (uint8_t)ch;
+            row8[24u + h] = (uint8_t)sym;
+          }
+        }
+      }
+      nfix = 0;
+      wave_lds_sync();
+    };
     // Order of the group's reads through the step loop: reads without a sequencing indel first, then the
-    // reads with one, then the reads with several (so that the two-window code and the event-list walk run
-    // in the few steps that need them instead of whenever one of a step's reads has an event, 42 % of the
-    // steps at XTen rates).
+    // reads with one, then the reads with several (so that the two-window code, the event-list walk and the
+    // computed bin offsets run in the few steps that need them instead of whenever one of a step's reads has
+    // an event, 42 % of the steps at XTen rates).
     const uint32_t nev_l = (my1.y >> 16) & 0x3Fu;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long in_group = G >= 64u ? ~0ull : ((1ull << G) - 1ull);
+    const unsigned long long in_group = (1ull << G) - 1ull;
     const unsigned long long m_multi = __ballot(items > 0u && nev_l >= 2u);
     const unsigned long long m_one = __ballot(items > 0u && nev_l == 1u);
     const unsigned long long m_rest = in_group & ~(m_multi | m_one);
@@ -1088,36 +1188,52 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       else pos = n_rest + n_one + (uint32_t)__popcll(m_multi & lt);
       perm[pos] = (uint8_t)lane;
     }
-    // STREAM: TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to
-    // the end of the stream (they fill lanes of the last step that would idle anyway); only reads longer
-    // than that take steps of their own below.
-    uint32_t n_ovf = 0;
-    unsigned long long more;
-    if (STREAM) {
-      const uint32_t extra = items > TI ? items - TI : 0u;
-      const bool small = extra == 1u || extra == 2u;
-      const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
-      if (small) {
-        const uint32_t o = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
-        ovf[o] = (uint16_t)(lane | (TI << 8));
-        if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
-      }
-      n_ovf = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-      more = __ballot(extra > 2u);
-    } else {
-      more = __ballot(items > TI);
+    // TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to the end of
+    // the stream (they fill lanes of the last step that would idle anyway); only reads longer than that take
+    // steps of their own below.
+    const uint32_t extra = items > TI ? items - TI : 0u;
+    const bool small = extra == 1u || extra == 2u;
+    const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
+    if (small) {
+      const uint32_t o = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+      ovf[o] = (uint16_t)(lane | (TI << 8));
+      if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
     }
+    const uint32_t n_ovf = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    unsigned long long more = __ballot(extra > 2u);
     wave_lds_sync();
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
-    const uint32_t nmain = STREAM ? (n_stream + 63u) / 64u : (n_fast + RPI - 1u) / RPI;
+    const uint32_t nmain = (n_stream + 63u) / 64u;
     uint32_t cb = TI;
-    // one item per lane; windows with a non-ACGT base (or, DIAG, a substitution) are queued for the
-    // generic code.  Two call sites -- the fixed map and the long-read tail -- so that the per-lane
-    // context constants of the fixed map stay loop-invariant registers.
-    auto run_item = [&](uint32_t r, uint32_t c, bool ok, const uint4 m0, const uint4 m1, uint32_t o0, uint32_t a0, uint32_t k0_,
-                        uint32_t o1, uint32_t a1, uint32_t k1_, uint32_t c_idle) {
-      const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
-      const bool active = ok && (m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+    // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
+    // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
+    struct Stage { uint32_t r, c; bool active; uint4 m0, m1; const uint8_t* src; uint4 w; };
+    auto fetch_item = [&](uint32_t r, uint32_t c, bool ok, uint32_t c_idle) -> Stage {
+      Stage st;
+      st.r = r;
+      st.m0 = meta_rows[r * 2];
+      st.m1 = meta_rows[r * 2 + 1];
+      const uint32_t nitems = ((st.m1.y & 0xFFFFu) + 7u) / 8u;
+      st.active = ok && (st.m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
+      st.c = st.active ? c : c_idle;
+      st.src = fast_src<PAIRED>(B, m, st.m0, st.m1, st.c, st.active);
+      __builtin_memcpy(&st.w, st.src, 16);
+      return st;
+    };
+    auto fetch_step = [&](uint32_t step) -> Stage {  // the item stream, 64 items per step
+      const uint32_t i = step * 64u + lane;
+      const bool ok = i < n_stream, in_map = i < n_items;
+      const uint32_t ri = __umul24(i, inv_TI) >> 20;  // i / TI (exact: i * TI < 2^20)
+      const uint32_t e = ovf[(ok && !in_map) ? i - n_items : 0u];
+      const uint32_t r = in_map ? perm[ri] : (ok ? (e & 0xFFu) : perm[0]);
+      const uint32_t c = in_map ? i - __umul24(ri, TI) : (ok ? e >> 8 : 1u);
+      return fetch_item(r, c, ok, c);
+    };
+    // windows with a non-ACGT base are queued for the generic code
+    auto run_item = [&](const Stage& st) {
+      const uint32_t r = st.r, c = st.c;
+      const uint4 m0 = st.m0, m1 = st.m1;
+      const bool active = st.active;
       // what the read's sequencing indels mean for this item (see fast_item)
       const uint32_t nev_r = active ? ((m1.y >> 16) & 0x3Fu) : 0u;
       int d0 = 0;
@@ -1143,54 +1259,58 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           if (n_in == 0u) d0 = -shift;
         }
       }
-      const bool slow = fast_item<PAIRED, DIAG, STREAM>(P, B, lds_sub, lds_qual, m, m0, m1, g * G + r, active ? c : c_idle, active, o0, a0, k0_,
-                                          o1, a1, k1_, meta_rows + r * 2, d0, n_in, ew_in, tj_in);
+      uint32_t fix, cw;
+      const bool slow = fast_item<PAIRED>(P, B, img, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
+                                          tj_in, st.src, st.w, fix, cw);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
         nslow += (uint32_t)__popcll(sm);
       }
-    };
-    if (STREAM) {
-      for (uint32_t step = 0; step < nmain; step++) {  // the item stream, 64 items per step
-        if (nslow > SLOW_CAP - 64u) flush_slow();
-        const uint32_t i = step * 64u + lane;
-        const bool ok = i < n_stream, in_map = i < n_items;
-        const uint32_t ri = __umul24(i, inv_TI) >> 20;  // i / TI (exact: i * TI < 2^20)
-        const uint32_t e = ovf[(ok && !in_map) ? i - n_items : 0u];
-        const uint32_t r = in_map ? perm[ri] : (ok ? (e & 0xFFu) : perm[0]);
-        const uint32_t c = in_map ? i - __umul24(ri, TI) : (ok ? e >> 8 : 1u);
-        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-        const bool head = c == 0u;
-        run_item(r, c, ok, m0, m1, head ? 10u : 6u, head ? 2u : 6u, head ? 0u : 20u, head ? 10u : 8u, head ? 4u : 6u, head ? 4u : 20u, c);
+      // flagged bases -> the group's fix-up list: read | base << 6 | bin << 9 | item << 17 (bins < 256: the table image
+      // would not fit LDS otherwise; items < 2^15), packed codes
+      unsigned long long fm = __ballot(fix != 0u);
+      while (fm) {
+        if (nfix + 64u > FIX_CAP) flush_fix();
+        if (fix != 0u) {
+          const uint32_t h = (uint32_t)__builtin_ctz(fix);
+          fix &= fix - 1u;
+          const uint32_t bin = __umulhi(__umul24(8u * c + h, bins), m1.z);
+          fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(r | (h << 6) | (bin << 9) | (c << 17), cw);
+        }
+        nfix += (uint32_t)__popcll(fm);
+        fm = __ballot(fix != 0u);
       }
-    } else {
-      for (uint32_t step = 0; step < nmain; step++) {  // RPI whole reads per step
+    };
+    if (nmain) {
+      Stage cur = fetch_step(0);
+      for (uint32_t step = 0; step < nmain; step++) {
         if (nslow > SLOW_CAP - 64u) flush_slow();
-        const uint32_t ri = step * RPI + sub;
-        const bool ok = lane_ok && ri < n_fast;
-        const uint32_t r = perm[ok ? ri : step * RPI];
-        const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-        run_item(r, c_lane, ok, m0, m1, hoff0, hw0, hk0, hoff1, hw1, hk1, c_lane);
+        // (the last step fetches itself again: an unconditional fetch keeps the loaded registers free of copies until
+        // the end of the iteration, so the wait for them sits after this step's sampling)
+        const Stage nxt = fetch_step(min(step + 1u, nmain - 1u));
+        run_item(cur);
+        cur = nxt;
       }
     }
-    while (more) {  // items past the fixed map (reads grown by insertions, reads of more than 64 items): never a first item
+    while (more) {  // items past the map (reads grown by insertions, reads of more than 64 items): never a first item
       if (nslow > SLOW_CAP - 64u) flush_slow();
       const uint32_t r = (uint32_t)__builtin_ctzll(more);
       const uint32_t c = cb + lane;
-      const uint4 m0 = meta_rows[r * 2], m1 = meta_rows[r * 2 + 1];
-      const uint32_t nitems = ((m1.y & 0xFFFFu) + 7u) / 8u;
+      const uint32_t nitems = ((meta_rows[r * 2 + 1].y & 0xFFFFu) + 7u) / 8u;
       cb += 64u;
       if (cb >= nitems) { more &= more - 1ull; cb = TI; }
-      run_item(r, c, true, m0, m1, 6u, 6u, 20u, 8u, 6u, 20u, 1u);
+      const Stage st = fetch_item(r, c, true, 1u);
+      run_item(st);
     }
     if (nslow) flush_slow();
+    if (nfix) flush_fix();
     // ---- per-read pass, lane = read: header text, last partial item, record separators ----
     // These byte-granular stores touch lines the steps above have just written from this wave, so
     // they merge in L2.  Reads whose last item went to the generic code (0xFFFFFFFF row) get only the
     // separators here; emit_slow_kernel writes the same separator bytes again (benign).
     wave_lds_sync();
-    if (lane < G && t < B.n_slots) {
+    if (lane < G && t < B.n_slots && !(B.diag & 2u)) {
       const uint4 r0 = meta_rows[lane * 2], r1 = meta_rows[lane * 2 + 1];
       if (r1.x & 0x7FFFFFFFu) {
         const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
@@ -1226,8 +1346,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
 
 // The queued items of emit_fast_kernel, one lane each, through the generic item code; the tables are
 // staged in LDS like in emit_kernel when they fit (persistent workgroup per CU, grid-stride over the queue).
-template <int KT, int QLG, bool SUB_LDS, bool QUAL_LDS>
-__global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t qual_words) {
+template <int KT, bool SUB_LDS>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, DevBatch B, uint32_t sub_rows) {
   extern __shared__ uint4 smem[];
   const uint32_t m = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
   const uint32_t tm = B.paired ? m : 0u;
@@ -1235,12 +1355,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, D
   if (n > B.slowq_cap) n = B.slowq_cap;  // overflow: the host reruns the batch through emit_kernel
   if ((blockIdx.x * EMIT_THREADS) >= n) return;  // nothing for this workgroup: skip the staging too
   uint4* lds_sub = smem;
-  uint32_t* lds_qual = (uint32_t*)(smem + (SUB_LDS ? sub_rows : 0u));
   const uint4* gsub = P.sub + (size_t)tm * P.sub_mate_rows;
   if (SUB_LDS)
     for (uint32_t i = tid; i < sub_rows; i += EMIT_THREADS) lds_sub[i] = gsub[i];
-  if (QUAL_LDS)
-    for (uint32_t i = tid; i < qual_words; i += EMIT_THREADS) lds_qual[i] = P.qual[i];
   __syncthreads();
   const uint2* q = B.slowq + (size_t)m * B.slowq_cap;
   for (uint32_t b0 = (blockIdx.x * EMIT_THREADS + tid) & ~63u; b0 < n; b0 += gridDim.x * EMIT_THREADS) {
@@ -1253,7 +1370,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, D
     const uint64_t ooff = B.recoff[idx];
     m0.z = (uint32_t)ooff;
     m0.w = (uint32_t)(ooff >> 32);
-    emit_item<KT, QLG, SUB_LDS, QUAL_LDS>(P, B, lds_sub, lds_qual, gsub, m, m0, m1, e.x, e.y, act);
+    emit_item<KT, SUB_LDS>(P, B, lds_sub, gsub, m, m0, m1, e.x, e.y, act);
   }
 }
 
@@ -1362,41 +1479,38 @@ void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* o
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, total);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk, 1), dim3(SCAN_BLOCK), 0, s, in, n, bsum, nblk, out);
 }
-// LDS budget of emit_kernel: tables that fit are staged, the rest is read through L2.
+// LDS budget: the generic kernels stage the substitution rows when they fit (the alias columns are read through L2);
+// the straight-line kernel needs its whole table image.
 static const size_t kLdsBytes = 160 * 1024;
-template <int KT, int QLG, bool SL, bool QL>
-static void launch_emit_variant(const DevProfile& P, const DevBatch& B, dim3 grid, size_t lds, uint32_t sub_rows,
-                                uint32_t qual_words, uint32_t TI, uint32_t RPI, hipStream_t s) {
-  (void)hipFuncSetAttribute((const void*)emit_kernel<KT, QLG, SL, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((emit_kernel<KT, QLG, SL, QL>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, qual_words, TI, RPI);
+template <int KT, bool SL>
+static void launch_emit_variant(const DevProfile& P, const DevBatch& B, dim3 grid, size_t lds, uint32_t sub_rows, uint32_t TI,
+                                uint32_t RPI, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)emit_kernel<KT, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((emit_kernel<KT, SL>), grid, dim3(EMIT_THREADS), lds, s, P, B, sub_rows, TI, RPI);
 }
-struct EmitLds { uint32_t sub_rows, qual_words, diag_words; size_t lds, lds_diag; bool sub_lds, qual_lds, diag_lds; };
+struct EmitLds { uint32_t sub_rows, fast_TI; size_t lds, lds_fast; bool sub_lds, fast_fits; };
 static EmitLds emit_lds(const DevProfile& P) {
   EmitLds e;
   uint32_t kmer_count = 0;
   for (int m = 1, p = 1; m <= P.kmer; m++) { p *= 4; kmer_count += p; }
   e.sub_rows = kmer_count * (uint32_t)P.bins;
-  e.qual_words = 16u * (uint32_t)P.bins * P.qual_stride;
-  e.diag_words = 4u * (uint32_t)P.bins * P.qual_stride;
-  const size_t fixed = (size_t)EMIT_WAVES * 64 * META_ROW + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * 64 +
-                       (size_t)EMIT_WAVES * 128 * 2;
-  const size_t sub_b = (size_t)e.sub_rows * 16, qual_b = ((size_t)e.qual_words * 4 + 15) & ~(size_t)15;
-  const size_t diag_b = ((size_t)e.diag_words * 4 + 15) & ~(size_t)15;
-  e.sub_lds = fixed + sub_b <= kLdsBytes;
-  e.qual_lds = e.sub_lds && fixed + sub_b + qual_b <= kLdsBytes;
-  e.diag_lds = e.sub_lds && fixed + sub_b + diag_b <= kLdsBytes;
-  e.lds = fixed + (e.sub_lds ? sub_b : 0) + (e.qual_lds ? qual_b : 0);
-  e.lds_diag = fixed + sub_b + diag_b;
+  const size_t meta_b = (size_t)EMIT_WAVES * 64 * META_ROW;
+  const size_t sub_b = (size_t)e.sub_rows * 16;
+  e.sub_lds = meta_b + sub_b <= kLdsBytes;
+  e.lds = meta_b + (e.sub_lds ? sub_b : 0);
+  // straight-line kernel: table image + look-up rows + character table + read rows + queues + read order + appended items
+  e.fast_TI = ((uint32_t)P.L + 7u) / 8u;
+  if (e.fast_TI > 64u) e.fast_TI = 64u;  // longer reads finish in steps of their own
+  const size_t img_b = (((size_t)P.bins * P.fast_stride + 3) & ~(size_t)3) * 4;
+  e.lds_fast = img_b + (size_t)e.fast_TI * LUT_ROW * 4 + 256 * 4 + meta_b + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * FIX_CAP * 8 +
+               (size_t)EMIT_WAVES * 64 + (size_t)EMIT_WAVES * 128 * 2;
+  e.fast_fits = P.kmer == 3 && P.fast_lds != nullptr && e.lds_fast <= kLdsBytes && P.bins < 256;
   return e;
 }
-// 0: generic kernel, 1: fast kernel with the whole 8-wide quality table in LDS, 2: fast kernel with the
-// diagonal quality rows in LDS (wide quality alphabets)
+// 0: generic kernel, 1: straight-line kernel
 static int emit_fast_mode(const DevProfile& P) {
-  const EmitLds e = emit_lds(P);
-  if (P.kmer != 3 || getenv("SG_DIAG") != nullptr) return 0;
-  if (P.qual_w == 8 && e.sub_lds && e.qual_lds) return 1;
-  if (P.qual_w <= 64 && e.diag_lds) return 2;
-  return 0;
+  if (getenv("SG_DIAG") != nullptr) return 0;
+  return emit_lds(P).fast_fits ? 1 : 0;
 }
 int emit_variant(const DevProfile& P) { return emit_fast_mode(P); }
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
@@ -1409,78 +1523,51 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     return;
   }
   const EmitLds e = emit_lds(P);
-  const uint32_t sub_rows = e.sub_rows, qual_words = e.qual_words;
-  const size_t lds = e.lds;
-  const bool sub_lds = e.sub_lds, qual_lds = e.qual_lds;
-  // fixed lane map: TI items of 8 bases per read, RPI reads per wave iteration
-  uint32_t TI = ((uint32_t)P.L + 3u + 7u) / 8u;
-  if (TI > 64u) TI = 64u;  // longer reads finish in the clean-up loop
-  const uint32_t RPI = 64u / TI;
-  const uint32_t G = RPI * (64u / RPI);
-  const uint32_t ngroups = (B.n_slots + G - 1u) / G;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const uint32_t nm = B.paired ? 2 : 1;
+  // generic kernel, fixed lane map: TI items of 8 bases per read, RPI reads per wave iteration
+  uint32_t TI = ((uint32_t)P.L + 3u + 7u) / 8u;
+  if (TI > 64u) TI = 64u;  // longer reads finish in the clean-up loop
+  const uint32_t RPI = 64u / TI;
+  const uint32_t G = RPI * (64u / RPI);
   uint32_t gx = (uint32_t)cus / nm;  // one 1024-thread workgroup per CU, persistent over read groups
   if (gx < 1) gx = 1;
-  const uint32_t need = (ngroups + EMIT_WAVES - 1) / EMIT_WAVES;
+  const uint32_t need = ((B.n_slots + G - 1u) / G + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
-  dim3 grid(gx, nm);
+  const dim3 grid(gx, nm);
   const int mode = force_generic ? 0 : emit_fast_mode(P);
-  // straight-line kernel, item-stream map by default: measured on the four shipped profiles it ties with the
-  // fixed map on XTen (4.91 vs 4.97 ms) and wins clearly with the diagonal-row variant (7.1 vs 9.2 ms
-  // HiSeq2500, 7.4 vs 10.5 ms HiSeq2000 / GAIIx).  SG_EMIT_MAP=fixed selects the other map (diagnostics).
-  bool stream = true;
-  if (const char* e = getenv("SG_EMIT_MAP")) stream = e[0] == 's';
-  // fixed map: three bases of slack in TI (a read that outgrows the map costs a whole extra step with one
-  // busy lane; at TI = ceil(L/8) that happened to 5 % of the XTen reads).  The stream map needs none: such
-  // items are appended to the stream.
-  uint32_t TIf = ((uint32_t)P.L + (stream ? 0u : 3u) + 7u) / 8u;
-  if (TIf > 64u) TIf = 64u;
-  const uint32_t RPIf = 64u / TIf;
-  const uint32_t Gf = stream ? 63u : RPIf * (64u / RPIf);
-  const uint32_t fneed = ((B.n_slots + Gf - 1u) / Gf + EMIT_WAVES - 1) / EMIT_WAVES;
-  uint32_t fgx = (uint32_t)cus / nm;
-  if (fgx < 1) fgx = 1;
-  if (fgx > fneed) fgx = fneed;
-  const dim3 fgrid(fgx, nm);
-  const uint32_t map_arg = stream ? (1u << 20) / TIf + 1u : RPIf;
-  auto launch_fast = [&](auto kern, size_t bytes, uint32_t qwords) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), bytes, s, P, B, sub_rows, qwords, TIf, map_arg);
-  };
-  auto pick = [&](auto paired_t, auto diag_t, size_t bytes, uint32_t qwords) {
-    constexpr bool PA = decltype(paired_t)::value, DG = decltype(diag_t)::value;
-    if (stream) launch_fast(emit_fast_kernel<PA, DG, true>, bytes, qwords);
-    else launch_fast(emit_fast_kernel<PA, DG, false>, bytes, qwords);
-  };
-  if (mode == 1) {
-    if (B.paired) pick(std::true_type{}, std::false_type{}, lds, qual_words);
-    else pick(std::false_type{}, std::false_type{}, lds, qual_words);
-  } else if (mode == 2) {
-    if (B.paired) pick(std::true_type{}, std::true_type{}, e.lds_diag, e.diag_words);
-    else pick(std::false_type{}, std::true_type{}, e.lds_diag, e.diag_words);
-  }
   if (mode != 0) {
-    if (after_main) (void)hipEventRecord(after_main, s);
-    // generic-code layout of the tables (no permutation): sub rows + the whole quality table when they fit
-    const size_t slow_sub = sub_lds ? (size_t)sub_rows * 16 : 0;
-    const size_t slow_qual = (sub_lds && slow_sub + (((size_t)qual_words * 4 + 15) & ~(size_t)15) <= kLdsBytes) ? (((size_t)qual_words * 4 + 15) & ~(size_t)15) : 0;
-    const dim3 sgrid(gx, nm);
-    auto launch_slow = [&](auto kern) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slow_sub + slow_qual));
-      hipLaunchKernelGGL(kern, sgrid, dim3(EMIT_THREADS), slow_sub + slow_qual, s, P, B, sub_rows, qual_words);
+    // straight-line kernel: item-stream map, 63 reads per group
+    const uint32_t TIf = e.fast_TI;
+    const uint32_t fneed = ((B.n_slots + 62u) / 63u + EMIT_WAVES - 1) / EMIT_WAVES;
+    uint32_t fgx = (uint32_t)cus / nm;
+    if (fgx < 1) fgx = 1;
+    if (fgx > fneed) fgx = fneed;
+    const dim3 fgrid(fgx, nm);
+    const uint32_t inv_TI = (1u << 20) / TIf + 1u;
+    auto launch_fast = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e.lds_fast);
+      hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), e.lds_fast, s, P, B, TIf, inv_TI);
     };
-    if (slow_sub && slow_qual && P.qual_w == 8) launch_slow(emit_slow_kernel<3, 3, true, true>);
-    else if (slow_sub && slow_qual) launch_slow(emit_slow_kernel<0, 0, true, true>);
-    else if (slow_sub) launch_slow(emit_slow_kernel<0, 0, true, false>);
-    else launch_slow(emit_slow_kernel<0, 0, false, false>);
-  } else if (P.kmer == 3 && P.qual_w == 8 && sub_lds && qual_lds) launch_emit_variant<3, 3, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
-  else if (sub_lds && qual_lds) launch_emit_variant<0, 0, true, true>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
-  else if (sub_lds) launch_emit_variant<0, 0, true, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
-  else launch_emit_variant<0, 0, false, false>(P, B, grid, lds, sub_rows, qual_words, TI, RPI, s);
-  if (mode == 0 && after_main) (void)hipEventRecord(after_main, s);
+    if (B.paired) launch_fast(emit_fast_kernel<true>);
+    else launch_fast(emit_fast_kernel<false>);
+    if (after_main) (void)hipEventRecord(after_main, s);
+    // the queued items through the generic code (reference-order tables)
+    const size_t slow_sub = e.sub_lds ? (size_t)e.sub_rows * 16 : 0;
+    auto launch_slow = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slow_sub);
+      hipLaunchKernelGGL(kern, grid, dim3(EMIT_THREADS), slow_sub, s, P, B, e.sub_rows);
+    };
+    if (slow_sub) launch_slow(emit_slow_kernel<3, true>);
+    else launch_slow(emit_slow_kernel<3, false>);
+  } else {
+    if (P.kmer == 3 && e.sub_lds) launch_emit_variant<3, true>(P, B, grid, e.lds, e.sub_rows, TI, RPI, s);
+    else if (e.sub_lds) launch_emit_variant<0, true>(P, B, grid, e.lds, e.sub_rows, TI, RPI, s);
+    else launch_emit_variant<0, false>(P, B, grid, e.lds, e.sub_rows, TI, RPI, s);
+    if (after_main) (void)hipEventRecord(after_main, s);
+  }
 }
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s) {  // bytes is a multiple of 16
   if (!bytes) return;

@@ -41,6 +41,32 @@ CompactRow encode_compact_row(const double* cdf, int ac);
 // Substitution row (N = 4): {T0, T1, T2, k0};  k = max(k0, (x>T0)+(x>T1)+(x>T2)).
 void encode_sub_row(const double* cdf4, uint32_t out[4]);
 
+// ---- measure-preserving rearrangements used by the per-base sampling ----
+// A CDF row of `ac` entries partitions the 2^32 draws: outcome k < ac-1 gets count_le(cdf[k]) - count_le(cdf[k-1])
+// of them, outcome ac-1 the rest (randIndx's fall-through).  Any draw -> outcome map that keeps these counts samples
+// the reference's distribution exactly.
+std::vector<uint64_t> row_masses(const double* cdf, int ac);
+
+// Substitution row, identity first: outcomes in the order o = [cd, the other base indexes ascending] (cd = the
+// reference base), cumulative masses c0 <= c1 <= c2 of o[0..2];  j = #{i : x >= c_i},  k = o[j].
+// Device form {D0, D1, D2}: j = max(j0, (x > D0) + (x > D1) + (x > D2)) with D_i = c_i - 1 and j0 = #{i : c_i == 0}.
+struct SubRow {
+  uint64_t c[3];
+  uint8_t order[4];
+  uint32_t D[3];
+  uint32_t j0;
+};
+SubRow encode_sub_row_identity_first(const double* cdf4, int cd);
+
+// Quality row as alias columns: W = 2^lgW columns of C = 2^32 / W draws; column col holds symbol lo for u < thr and hi
+// for u >= thr (col = x >> (32 - lgW), u = x & (C - 1)); canonical: thr in [0, C), lo == hi when thr == 0.
+struct AliasRow {
+  std::vector<uint32_t> thr;
+  std::vector<uint8_t> lo, hi;
+};
+uint32_t symbols_with_mass(const std::vector<uint64_t>& masses);
+AliasRow build_alias_row(const std::vector<uint64_t>& masses, uint32_t lgW);  // throws std::runtime_error if masses do not fit
+
 inline uint32_t pow2_at_least(uint32_t n) {
   uint32_t p = 1;
   while (p < n) p <<= 1;

@@ -52,13 +52,12 @@ def _stat(stderr, key):
 def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
     """The straight-line emit kernel queues the items it cannot do (non-ACGT windows, >= 2 indels) for
     emit_slow_kernel; a queue too small makes the engine emit the batch again with the generic kernel.
-    Both routes, the generic kernel alone (SG_DIAG=0) and the straight-line kernel with its other lane map
-    (SG_EMIT_MAP=fixed) must write the same bytes, and so must a run whose batches are cut into many
-    memory-bounded pieces (SIMU_PIECE_SLOTS)."""
+    Both routes and the generic kernel alone (SG_DIAG=0) must write the same bytes, and so must a run whose
+    batches are cut into many memory-bounded pieces (SIMU_PIECE_SLOTS)."""
     cfg = cases.build_case(name, str(tmp_path))
     outs = {}
     for tag, extra_env in (("queue", {}), ("overflow", {"SG_SLOWQ_CAP": "3"}), ("generic", {"SG_DIAG": "0"}),
-                           ("fixed_map", {"SG_EMIT_MAP": "fixed"}), ("pieces", {"SIMU_PIECE_SLOTS": "1500"})):
+                           ("pieces", {"SIMU_PIECE_SLOTS": "1500"})):
         d = str(tmp_path / tag)
         err = _run_gpu(cfg, d, env=dict(os.environ, **extra_env))
         outs[tag] = {f: open(os.path.join(d, f), "rb").read() for f in _files(d)}
@@ -68,7 +67,7 @@ def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
             assert _stat(err, "requeued_batches") > 0, err
         if tag == "generic":
             assert _stat(err, "queued_items") == 0, err
-    assert outs["queue"] == outs["overflow"] == outs["generic"] == outs["fixed_map"] == outs["pieces"] and outs["queue"]
+    assert outs["queue"] == outs["overflow"] == outs["generic"] == outs["pieces"] and outs["queue"]
 
 
 def _records(blob):

@@ -1,4 +1,5 @@
 #!/bin/bash
-# usage: pmc_quick.sh <tag> -- one SQ counter pass over bench.py (instruction mix of the kernels)
+# usage: pmc_quick.sh <tag> -- SQ counter passes over bench.py (instruction mix, wave states, clock of the kernels)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_$1_SQ_WAVE_CYCLES -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmc_$1.err || echo "pmc failed"
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_$1_SQ_INSTS_LDS -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmc_$1b.err || echo "pmc b failed"
