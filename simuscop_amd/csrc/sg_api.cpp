@@ -39,6 +39,7 @@ void launch_ref_ingest(const uint8_t* raw, uint8_t* codes, const void* contigs, 
 void launch_hap_copy(uint8_t* chains, const uint8_t* ref_codes, const uint8_t* literals, const void* pieces, uint64_t n, hipStream_t s);
 void launch_hap_patch(uint8_t* chains, const void* patches, uint64_t n, hipStream_t s);
 void launch_encode_bytes(uint8_t* buf, uint64_t n, hipStream_t s);
+void launch_pack2(const uint8_t* chains, uint64_t bytes, uint32_t* fwd2, uint32_t* rc2, uint16_t* bad, hipStream_t s);
 // sg_deflate.hip
 struct DevDeflate {
   const uint8_t* text; uint64_t bytes; uint32_t n_chunks;
@@ -97,7 +98,7 @@ struct sg_ctx {
   bool have_profile = false, have_haps = false, have_plan = false, sampled = false;
   sg::DevProfile P{};
   sg::DevBatch B{};
-  DevBuf tab, chains, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
+  DevBuf tab, chains, chains2, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
       recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work, gz1, gz2, gz_work;
   uint64_t gz_bytes[2] = {0, 0};
   bool gz_valid = false;
@@ -132,6 +133,19 @@ struct sg_ctx {
     int _e = (buf).ensure(bytes);                                                              \
     if (_e) return ctx->hipfail((hipError_t)_e, "hipMalloc(" #buf ")");                        \
   } while (0)
+
+// 2-bit copies of the chains buffer (`total` bytes, a multiple of 1024) for the straight-line emit kernel
+static int pack_chains(sg_ctx* ctx, size_t total) {
+  const size_t q = total / 4, badb = total / 64 / 8;
+  SG_ENSURE(ctx->chains2, 2 * q + badb + 64);
+  uint8_t* p = ctx->chains2.as<uint8_t>();
+  sg::launch_pack2(ctx->chains.as<uint8_t>(), total, (uint32_t*)p, (uint32_t*)(p + q), (uint16_t*)(p + 2 * q), ctx->stream);
+  ctx->B.chains2_fwd = p;
+  ctx->B.chains2_rc = p + q;
+  ctx->B.chains_bad = (const uint16_t*)(p + 2 * q);
+  ctx->B.chains_total = total;
+  return SG_OK;
+}
 
 extern "C" {
 
@@ -187,7 +201,7 @@ void sg_destroy(sg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
+  for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chains2, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
                     &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq,
                     &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work, &ctx->gz1, &ctx->gz2, &ctx->gz_work})
@@ -723,7 +737,7 @@ int sg_build_haplotypes(sg_ctx* ctx, int32_t n_chains, const uint64_t* lens, con
     total += (lens[c] + PAD + 63) & ~(size_t)63;
   }
   total += PAD;
-  total = (total + 15) & ~(size_t)15;
+  total = (total + 1023) & ~(size_t)1023;
   // absolute offsets, long pieces split so that every workgroup moves <= 64 KB; coverage is checked
   // by summing the piece lengths per chain after a bounds check of each piece
   const uint32_t kSplit = 1u << 16;
@@ -772,6 +786,7 @@ int sg_build_haplotypes(sg_ctx* ctx, int32_t n_chains, const uint64_t* lens, con
   SG_HIP(hipMemcpyAsync(ctx->chain_meta.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   sg::launch_hap_copy(ctx->chains.as<uint8_t>(), ctx->ref_codes.as<uint8_t>(), wk + pieces_b + patches_b, wk, dp.size(), ctx->stream);
   sg::launch_hap_patch(ctx->chains.as<uint8_t>(), wk + pieces_b, pt.size(), ctx->stream);
+  if (int rc = pack_chains(ctx, total)) return rc;
   SG_HIP(hipGetLastError());
   SG_HIP(hipStreamSynchronize(ctx->stream));  // dp / pt / meta are stack-owned host memory
   ctx->B.chains = ctx->chains.as<uint8_t>();
@@ -810,15 +825,16 @@ int sg_upload_haplotypes(sg_ctx* ctx, int32_t n_chains, const char* const* chain
     total += (lens[c] + PAD + 63) & ~(size_t)63;
   }
   total += PAD;
+  total = (total + 1023) & ~(size_t)1023;
   SG_ENSURE(ctx->chains, total);
   SG_ENSURE(ctx->chain_meta, meta.size() * 8);
-  total = (total + 15) & ~(size_t)15;
   SG_HIP(hipMemsetAsync(ctx->chains.p, 'N', total, ctx->stream));
   for (int c = 0; c < n_chains; c++)
     if (lens[c]) SG_HIP(hipMemcpyAsync((uint8_t*)ctx->chains.p + meta[c], chains[c], lens[c], hipMemcpyHostToDevice, ctx->stream));
   SG_HIP(hipMemcpyAsync(ctx->chain_meta.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   // ASCII -> base codes, in place (A0 C1 T2 G3, N=4, other=5): the kernels never see ASCII
   sg::launch_encode((uint8_t*)ctx->chains.p, total, ctx->stream);
+  if (int rc = pack_chains(ctx, total)) return rc;
   SG_HIP(hipGetLastError());
   SG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->B.chains = ctx->chains.as<uint8_t>();

@@ -52,6 +52,12 @@ struct DevBatch {
   const uint8_t* chains;        // all chains, each padded; chain c starts at chain_off[c]
   const uint64_t* chain_off;
   const uint64_t* chain_len;
+  // 2-bit copies of the whole chains buffer for the straight-line emit kernel (pack2_kernel): forward, reverse
+  // complement (base j = complement of base chains_total - 1 - j), and one "not all A/C/G/T" bit per 64 bases
+  const uint8_t* chains2_fwd;
+  const uint8_t* chains2_rc;
+  const uint16_t* chains_bad;
+  uint64_t chains_total;
   const sg_window* windows;
   uint64_t n_windows;
   const uint32_t* seg_size;
@@ -75,7 +81,8 @@ struct DevBatch {
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
   uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
-  uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full)
+  uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full); [4] slow-queue counts;
+                                // [5],[6] group counters of the emit kernels
   uint2* slowq;                 // [2][slowq_cap] (slot, item) left to emit_slow_kernel by the fast emit kernel
   uint32_t* slowq_count;        // [2] entries appended per mate (may exceed slowq_cap: overflow)
   uint32_t slowq_cap;

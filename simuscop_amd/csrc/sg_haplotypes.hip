@@ -130,6 +130,38 @@ __global__ __launch_bounds__(256) void encode_bytes_kernel(uint8_t* __restrict__
     buf[i] = (uint8_t)encode_base(buf[i]);
 }
 
+// ---- 2-bit copies for the straight-line emit kernel ---------------------------------------------------
+// lane = 16 consecutive bases of the chains buffer (T bytes, a multiple of 1024, guard bytes included):
+//   fwd2  base a at bits 2 (a % 16) of word a / 16, code & 3;
+//   rc2   the reverse complement of the WHOLE buffer, rc2 base j = complement of base T - 1 - j: a reverse read of the
+//         fragment [A, A + n) is the forward read at T - A - n of rc2 (complement in code space = xor 2);
+//   bad   one bit per 64 bases: some base of the block is not A/C/G/T (reads touching such a block take the generic code).
+__global__ __launch_bounds__(256) void pack2_kernel(const uint8_t* __restrict__ chains, uint64_t n16, uint32_t* __restrict__ fwd2,
+                                                    uint32_t* __restrict__ rc2, uint16_t* __restrict__ bad) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // n16 is a multiple of 64: whole waves
+  if (g >= n16) return;
+  const uint4 w = *(const uint4*)(chains + g * 16);
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+  uint32_t word = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t v = ws[k] & 0x03030303u;
+    word |= ((v | (v >> 6) | (v >> 12) | (v >> 18)) & 0xFFu) << (8 * k);
+  }
+  const bool any_bad = ((w.x | w.y | w.z | w.w) & 0xFCFCFCFCu) != 0u;
+  fwd2[g] = word;
+  uint32_t r = __builtin_bitreverse32(word);                       // field order reversed, the two bits of a field swapped
+  r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);         // swap them back
+  rc2[n16 - 1 - g] = r ^ 0xAAAAAAAAu;                              // A0 <-> T2, C1 <-> G3
+  const unsigned long long b = __ballot(any_bad);                  // one bit per 16 bases, 1024 bases per wave
+  if ((threadIdx.x & 63u) == 0u) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m |= (uint32_t)(((b >> (4 * k)) & 0xFull) != 0ull) << k;
+    bad[g >> 6] = (uint16_t)m;
+  }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------
 static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t max_blocks) {
   uint64_t g = (items + per_block - 1) / per_block;
@@ -153,6 +185,11 @@ void launch_hap_copy(uint8_t* chains, const uint8_t* ref_codes, const uint8_t* l
 void launch_hap_patch(uint8_t* chains, const void* patches, uint64_t n, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(hap_patch_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, chains, (const DevPatch*)patches, n);
+}
+void launch_pack2(const uint8_t* chains, uint64_t bytes, uint32_t* fwd2, uint32_t* rc2, uint16_t* bad, hipStream_t s) {  // bytes % 1024 == 0
+  const uint64_t n16 = bytes / 16;
+  if (!n16) return;
+  hipLaunchKernelGGL(pack2_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, s, chains, n16, fwd2, rc2, bad);
 }
 void launch_encode_bytes(uint8_t* buf, uint64_t n, hipStream_t s) {
   if (!n) return;

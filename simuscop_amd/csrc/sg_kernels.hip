@@ -259,11 +259,20 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
   const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
   const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
+  // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
+  // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
+  // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
+  uint32_t touches_bad = 0;
+  {
+    const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
+    for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
+  }
   B.meta[idx * 4] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
   // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
   // (sg_load_profile rejects profiles that could violate the bound)
   // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
-  B.meta[idx * 4 + 1] = make_uint4(flen | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u, nev == 1u ? first_ev : 0u);
+  B.meta[idx * 4 + 1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
+                                   nev == 1u ? first_ev : 0u);
   if (hdr <= 32u) {
     uint32_t* hp = (uint32_t*)(B.meta + idx * 4 + 2);
     uint32_t w = 0, nb = 0;
@@ -457,11 +466,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 #define EMIT_WAVES (EMIT_THREADS / 64)
 #define META_ROW 32  // bytes of LDS metadata per read
 
-// Orders one wave's LDS writes before its later LDS reads by other lanes (wave-private staging rows).
+// Orders one wave's LDS writes before its later LDS reads by other lanes (wave-private staging rows).  Wavefront scope:
+// the LDS executes one wave's operations in issue order, so only the compiler has to be held back -- a workgroup-scope
+// fence would also wait for every global store the wave has in flight (s_waitcnt vmcnt(0)), several times per read group.
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Source codes of a read that carries sequencing-indel events (rare path, kept OUT OF LINE and
@@ -524,7 +535,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   const uint32_t K = KT ? (uint32_t)KT : (uint32_t)P.kmer;
   const uint32_t bins = (uint32_t)P.bins;
   const uint32_t ctxmask = (1u << (2 * K)) - 1u;
-  const uint32_t flen = m1.x & 0x7FFFFFFFu;
+  const uint32_t flen = m1.x & 0x3FFFFFFFu;  // bit 30: the read touches a non-ACGT block (straight-line kernel only)
   const bool rev = (m1.x >> 31) != 0;
   const uint32_t np = m1.y & 0xFFFFu, nev = (B.diag & 32u) ? 0u : ((m1.y >> 16) & 0x3Fu), hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
@@ -786,6 +797,8 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..
   return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 #define FAST_CTX 192u  // context rows per bin: [0,64) three bases, [64,128) two bases (x4), [128,192) one base (x16)
 #define LUT_ROW 12u    // dwords per item in the look-up row: so[0..7], qo[0..1], 2 unused
 
@@ -802,25 +815,24 @@ __device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h
   return l == 0u ? y[0] : l == 1u ? y[1] : l == 2u ? y[2] : y[3];
 }
 
-// Address of an item's un-shifted template window: 16 encoded haplotype bytes such that, after the byte reversal of
-// reverse reads, output position p sits at byte p - 8c + 5.  Idle lanes read a harmless in-bounds address.
+// Base index of an item's un-shifted template window in the 2-bit copy the read walks forwards -- the forward copy, or
+// for a reverse read the reverse-complement copy, where the fragment [A, A + n) starts at total - A - n: output
+// position p of the read is base `index + p - 8c + 5` of that copy.  Idle lanes read a harmless in-bounds index.
 template <bool PAIRED>
-__device__ __forceinline__ const uint8_t* fast_src(const DevBatch& B, uint32_t m, const uint4 m0, const uint4 m1, uint32_t c, bool active) {
-  const uint32_t flen = m1.x & 0x7FFFFFFFu;
+__device__ __forceinline__ uint32_t fast_src(const DevBatch& B, uint32_t m, const uint4 m0, const uint4 m1, uint32_t c, bool active) {
+  const uint32_t flen = m1.x & 0x3FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
-  const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
-  const int i0 = (int)(8u * c);
-  return !active ? B.chains + 128 : (rev ? frag + (int)flen - i0 - 11 : frag + i0 - 5);
+  const uint32_t a = rev ? (uint32_t)B.chains_total - m0.x - flen : m0.x;  // the straight-line kernel runs on buffers < 2^31 bases
+  return active ? a + 8u * c - 5u : 128u;
 }
 
 template <bool PAIRED>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint32_t* img, const uint32_t* lut,
                                           const uint32_t* code4, uint32_t TI, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint4* tail_row, int d0, uint32_t n_in,
-                                          uint32_t ew_in, uint32_t tj_in, const uint8_t* src0, uint4 wpre, uint32_t& fix,
-                                          uint32_t& cw_out) {
+                                          uint32_t ew_in, uint32_t tj_in, uint32_t src0, uint2 wpre,
+                                          __amdgpu_buffer_rsrc_t out_rsrc, uint32_t& fix, uint32_t& cw_out) {
   const uint32_t bins = (uint32_t)P.bins;
-  const uint32_t flen = m1.x & 0x7FFFFFFFu;
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
   // An idle lane may be looking at a row whose read is finished; its fragment offset, reciprocal and event word then
   // hold the parked last item (see below), so an idle lane must not follow them -- it reads a harmless in-bounds
@@ -831,35 +843,23 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   const uint32_t np = m1.y & 0xFFFFu, nev = active ? n_in : 0u, hdr = m1.y >> 22;
   const uint32_t inv = m1.z;
   const uint32_t i0 = 8u * c;
-  // src0 = the item's un-shifted template window (fast_src), already loaded into wpre by the caller one step ahead;
-  // events before the item shift it by d0
-  const uint8_t* src = rev ? src0 - d0 : src0 + d0;
-  (void)flen;
-
-  // 16 encoded bytes -> byte order by position (reverse reads), complement, validity, 2-bit pack
-  auto pack_window = [&](uint4 v, uint32_t& bad) -> uint32_t {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if (rev) {  // PAIRED: wave-uniform branch
-      const uint32_t t0 = __builtin_bswap32(w[3]) ^ 0x02020202u, t1 = __builtin_bswap32(w[2]) ^ 0x02020202u;
-      const uint32_t t2 = __builtin_bswap32(w[1]) ^ 0x02020202u, t3 = __builtin_bswap32(w[0]) ^ 0x02020202u;
-      w[0] = t0; w[1] = t1; w[2] = t2; w[3] = t3;
-    }
-    // positions i0-2 .. i0+7 are bytes 3..12 (complementing an invalid code 4/5 gives 6/7: still >= 4)
-    bad = (w[0] & 0xFC000000u) | ((w[1] | w[2]) & 0xFCFCFCFCu) | (w[3] & 0xFCu);
-    return pack4(w[0]) | (pack4(w[1]) << 8) | (pack4(w[2]) << 16) | ((w[3] & 3u) << 24);
+  // 13 source codes, 2 bits each, for output positions i0-5 .. i0+7: 26 bits of the 2-bit copy starting at base index
+  // src (src0 = the un-shifted window, fast_src, already loaded into wpre by the caller one step ahead; events before
+  // the item shift it by d0).  Reads touching a non-ACGT block never get here with valid codes: they are queued whole.
+  const uint8_t* copy2 = rev ? B.chains2_rc : B.chains2_fwd;
+  auto window = [&](uint32_t idx) -> uint32_t {
+    uint2 v;
+    __builtin_memcpy(&v, copy2 + (idx >> 2), 8);
+    return (uint32_t)((((uint64_t)v.y << 32) | v.x) >> (2u * (idx & 3u)));
   };
-  auto window = [&](const uint8_t* p16, uint32_t& bad) -> uint32_t {
-    uint4 v;
-    __builtin_memcpy(&v, p16, 16);
-    return pack_window(v, bad);
-  };
+  const uint32_t src = src0 + (uint32_t)d0;
   if (__ballot(d0 != 0) != 0ull) {
-    if (d0 != 0) __builtin_memcpy(&wpre, src, 16);
+    if (d0 != 0) __builtin_memcpy(&wpre, copy2 + (src >> 2), 8);
   }
-  uint32_t bad;
+  const uint32_t bad = (m1.x >> 30) & 1u;
   uint32_t cw;
-  if (B.diag & 4u) { cw = slot * 2654435761u + c; bad = 0; }  // ablation: no haplotype fetch
-  else cw = pack_window(wpre, bad);
+  if (B.diag & 4u) cw = slot * 2654435761u + c;  // ablation: no haplotype fetch
+  else cw = (uint32_t)((((uint64_t)wpre.y << 32) | wpre.x) >> (2u * (src & 3u)));
 
   // reads with exactly one sequencing indel: past the event the window is shifted by +-len
   if (__ballot(nev == 1u) != 0ull) {
@@ -868,9 +868,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
       const int ej = (int)(ew & 0xFFFFu), elen = (int)((ew >> 16) & 0x7FFFu);
       const bool del = (ew >> 31) != 0;
       const int delta = del ? elen : -elen;
-      uint32_t bad2;
-      const uint32_t cw2 = window(rev ? src - delta : src + delta, bad2);
-      bad |= bad2;
+      const uint32_t cw2 = window(src + (uint32_t)delta);
       const int first_shifted = del ? ej : ej + elen + 1;       // first output position reading the shifted window
       const int q0 = first_shifted - ((int)i0 - 5);               // its index in the item window
       const uint32_t keep = q0 <= 0 ? 0u : (q0 >= 13 ? 0xFFFFFFFFu : ((1u << (2 * q0)) - 1u));
@@ -968,21 +966,24 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   const bool go = active && !slow;
   qw[0] += 0x01010101u * (uint32_t)P.min_qual;
   qw[1] += 0x01010101u * (uint32_t)P.min_qual;
-  // A whole item is two 8-byte stores.  The read's last, partial item (np % 8 bases) is parked in the
-  // read's own LDS row instead: the per-read pass after the step loop merges it with the record
-  // separators, so the byte-granular stores run once per read group rather than in every step.
-  if (active) {
-    if (i0 + 8u <= np) {
-      if (go && !(B.diag & 1u)) {
-        const uint64_t S = ((uint64_t)sw[1] << 32) | sw[0], Q = ((uint64_t)qw[1] << 32) | qw[0];
-        uint8_t* so_ = B.out[m] + (((uint64_t)m0.w << 32) | m0.z) + hdr + i0;
-        uint8_t* qo_ = so_ + np + 3u;
-        __builtin_memcpy(so_, &S, 8);
-        __builtin_memcpy(qo_, &Q, 8);
-      }
-    } else {
-      // parked in the read's own LDS row, over the fields no lane needs once the last item has been
-      // sampled (fragment offset, 2^32/n', event): base characters are never 0xFF
+  // A whole item is two 8-byte stores.  They are buffer stores through the read group's descriptor (base = the group's
+  // first record, offsets 32-bit), issued by EVERY lane on every path: a lane with nothing to store gives an offset past
+  // the descriptor's range and the hardware drops it.  The step loop so holds a fixed number of vector-memory
+  // operations, and the wait for the next step's prefetched window is a counted s_waitcnt (vmcnt(3)) instead of one
+  // that also drains these stores (with the stores under a branch the compiler had to assume the path without them:
+  // vmcnt(1), a full store round trip exposed in every step).  The read's last, partial item (np % 8 bases) is parked
+  // in the read's own LDS row: the per-read pass after the step loop merges it with the record separators, so the
+  // byte-granular stores run once per read group rather than in every step.
+  {
+    const bool whole = i0 + 8u <= np;
+    const bool st = go && whole && !(B.diag & 1u);
+    const uint32_t so_ = st ? m0.z + hdr + i0 : 0xFFFFFFFFu;
+    const uint32_t qo_ = st ? so_ + np + 3u : 0xFFFFFFFFu;
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, so_, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, qo_, 0, 0);
+    if (active && !whole) {
+      // parked over the fields no lane needs once the last item has been sampled (fragment offset, 2^32/n',
+      // event): base characters are never 0xFF
       tail_row[0].x = slow ? 0xFFFFFFFFu : sw[0];
       tail_row[0].y = sw[1];
       tail_row[1].z = qw[0];
@@ -1066,15 +1067,22 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
+    uint64_t ooff = 0;
     if (lane < G && t < B.n_slots) {
       const size_t idx = (size_t)m * B.n_slots + t;
       my0 = B.meta[idx * 4];
       my1 = B.meta[idx * 4 + 1];
-      const uint64_t ooff = B.recoff[idx];
-      my0.z = (uint32_t)ooff;
-      my0.w = (uint32_t)(ooff >> 32);
+      ooff = B.recoff[idx];
       if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
     }
+    // The group's text is one contiguous range starting at its first record: a buffer descriptor on that address, the
+    // records at 32-bit offsets from it (row word 2).  Offsets past 2^31 are the "no store" value of idle lanes.
+    const uint64_t gbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ooff >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ooff);
+    uint8_t* const gout = B.out[m] + gbase;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(gout, 0, 0x80000000u, 0x00020000);
+    my0.z = (uint32_t)(ooff - gbase);
+    my0.w = 0;
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
     wave_lds_sync();
@@ -1155,7 +1163,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           const uint4 r0 = meta_rows[r * 2], r1 = meta_rows[r * 2 + 1];
           const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22, i = 8u * c + h;
           if (8u * c + 8u <= np) {
-            uint8_t* rec = B.out[m] + (((uint64_t)r0.w << 32) | r0.z) + hl + i;
+            uint8_t* rec = gout + r0.z + hl + i;
             rec[0] = (uint8_t)ch;
             rec[np + 3u] = (uint8_t)sym;
           } else if (r0.x != 0xFFFFFFFFu) {
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
     // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
-    struct Stage { uint32_t r, c; bool active; uint4 m0, m1; const uint8_t* src; uint4 w; };
+    struct Stage { uint32_t r, c; bool active; uint4 m0, m1; uint32_t src; uint2 w; };
     auto fetch_item = [&](uint32_t r, uint32_t c, bool ok, uint32_t c_idle) -> Stage {
       Stage st;
       st.r = r;
@@ -1217,7 +1225,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       st.active = ok && (st.m1.x & 0x7FFFFFFFu) != 0u && c < nitems;
       st.c = st.active ? c : c_idle;
       st.src = fast_src<PAIRED>(B, m, st.m0, st.m1, st.c, st.active);
-      __builtin_memcpy(&st.w, st.src, 16);
+      __builtin_memcpy(&st.w, (((PAIRED ? m == 1u : (st.m1.x >> 31) != 0u)) ? B.chains2_rc : B.chains2_fwd) + (st.src >> 2), 8);
       return st;
     };
     auto fetch_step = [&](uint32_t step) -> Stage {  // the item stream, 64 items per step
@@ -1261,7 +1269,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
       uint32_t fix, cw;
       const bool slow = fast_item<PAIRED>(P, B, img, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
-                                          tj_in, st.src, st.w, fix, cw);
+                                          tj_in, st.src, st.w, out_rsrc, fix, cw);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
@@ -1284,6 +1292,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     };
     if (nmain) {
       Stage cur = fetch_step(0);
+      // two (dropped) stores: the loop is then entered with the same three vector-memory operations behind the first
+      // prefetch as every later iteration has behind its own (two item stores + the next prefetch), and the wait for a
+      // prefetched window stays vmcnt(3) instead of falling back to the entry path's vmcnt(1)
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
       for (uint32_t step = 0; step < nmain; step++) {
         if (nslow > SLOW_CAP - 64u) flush_slow();
         // (the last step fetches itself again: an unconditional fetch keeps the loaded registers free of copies until
@@ -1314,7 +1327,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint4 r0 = meta_rows[lane * 2], r1 = meta_rows[lane * 2 + 1];
       if (r1.x & 0x7FFFFFFFu) {
         const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
-        uint8_t* rec = B.out[m] + (((uint64_t)r0.w << 32) | r0.z);
+        uint8_t* rec = gout + r0.z;
         if (hl <= 32u) {
           const uint4* hrow = B.meta + ((size_t)m * B.n_slots + t) * 4 + 2;
           const uint4 h0 = hrow[0], h1 = hrow[1];
@@ -1514,8 +1527,8 @@ static int emit_fast_mode(const DevProfile& P) {
 }
 int emit_variant(const DevProfile& P) { return emit_fast_mode(P); }
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B) {
-  (void)B;
-  return emit_fast_mode(P) != 0;
+  // the straight-line kernel addresses the 2-bit haplotype copies with 32-bit base indexes
+  return emit_fast_mode(P) != 0 && B.chains_total < (1ull << 31);
 }
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main) {
   if (!B.n_slots) {
@@ -1537,7 +1550,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
   const uint32_t need = ((B.n_slots + G - 1u) / G + EMIT_WAVES - 1) / EMIT_WAVES;
   if (gx > need) gx = need;
   const dim3 grid(gx, nm);
-  const int mode = force_generic ? 0 : emit_fast_mode(P);
+  const int mode = (force_generic || !emit_uses_fast_kernel(P, B)) ? 0 : 1;
   if (mode != 0) {
     // straight-line kernel: item-stream map, 63 reads per group
     const uint32_t TIf = e.fast_TI;
