@@ -5,13 +5,18 @@ Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C2"): one synthetic contig o
 (64,444,167 bp), HiSeqXTen profile (151 bp), PE, 30x, insertSize 350 -> ~6.4 M pairs per step.
 A step = one full sampling pass over that chromosome (plan draws, indel pass, offset scan, per-base
 substitution/quality sampling, FASTQ formatting) with haplotypes, tables and plan already resident in
-HBM; FASTQ text stays in HBM (PCIe/file rates are reported separately in DESIGN.md).
+HBM.  `value` counts a pair when its FASTQ text is complete in HBM (inputs resident, no PCIe in the
+timed region).  SURVEY 8(d)'s own metric -- pairs whose text is complete in a PINNED HOST buffer -- is
+measured in the same run right after (`host_pinned`: every pass drained through detached output sets while
+the next pass is sampled, plain and block-gzipped on the device first), with the PCIe rate it achieved.
 
-Multi-GPU (torchrun, one rank per GPU): weak scaling -- every rank owns one chr20-sized chromosome
-of an N-chromosome genome.  The only exchange is the read-count balancing step of
-Genome::setReadCounts (Genome.cpp:783-825): an all_gather of the per-chromosome GC-weighted lengths
-over RCCL, after which every rank derives its read count exactly as the reference apportions
-`reads*chrWL/WL`.  No data-path collective.
+Multi-GPU (`--gpus N`: one rank per GPU over torchrun; started by the driver or by this script itself):
+weak scaling -- every rank owns one chr20-sized chromosome of an N-chromosome genome.  The only exchange
+is the read-count balancing step of Genome::setReadCounts (Genome.cpp:783-825): an all_gather of the
+per-chromosome GC-weighted lengths over RCCL, after which every rank derives its read count exactly as
+the reference apportions `reads*chrWL/WL`.  No data-path collective.
+`--workload c3` is strong scaling of ONE 24-contig genome in GRCh38 proportions (`--scale`), whole run
+including ingest: ranks own whole contigs balanced by length, ingest only those (simuReads --rank/--world).
 """
 from __future__ import annotations
 
@@ -21,6 +26,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +35,9 @@ sys.path.insert(0, ROOT)
 CHR20_LEN = 64444167
 TESTDATA = os.path.join(ROOT, "tests", "golden", "testData")
 BYTES_PER_PAIR_FMT = "2*L haplotype bytes read + 2 FASTQ records written"
-
+# issue cost of one VALU wave-instruction in this kernel's instruction mix, cycles per SIMD (tools/valu_microbench.hip:
+# 2.3 for add/sub/logic/right shift alone, 4.2 for everything else, ~4.2 for any realistic mixture of the two)
+VALU_CYCLES_PER_INSTRUCTION = 4.2
 
 PROFILES = {  # name -> (file, read length)
     "xten": ("Illumina_HiSeqXTen.profile", 151), "hs2500": ("Illumina_HiSeq2500.profile", 125),
@@ -43,14 +51,16 @@ def write_config(path, fasta, out_dir, coverage=30, threads=1, profile="Illumina
                 f"layout = PE\nthreads = {threads}\nverbose = 0\ncoverage = {coverage}\ninsertSize = 350\n")
 
 
-def cpu_baseline(workdir, cores, profile="Illumina_HiSeqXTen.profile"):
-    """Time the reference's CPU thread-pool path on a bounded sample of the same workload.
+def cpu_baseline(workdir, profile="Illumina_HiSeqXTen.profile"):
+    """Time the reference's CPU thread-pool path on a bounded sample of the same workload, on ALL host cores.
 
     Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
-    Fallback (binary absent): the oracle restatement (kind "port").  Sample: a 48 Mbp contig of the
-    same synthetic genome at 30x (one <=1 Mbp segment per worker thread, Genome.cpp:876-883)."""
+    Fallback (binary absent): the oracle restatement (kind "port").  Sample: ONE contig of the same synthetic
+    genome at 30x with one <=1 Mbp segment per worker thread -- the reference's unit of parallelism is the segment,
+    with a barrier per chromosome (Genome.cpp:876-883), so a chromosome shorter than `cores` Mbp leaves cores idle."""
     from simuscop_amd import synth
-    sample_len = 48_000_000   # ~15 s of reference CPU time on 16 threads
+    cores = os.cpu_count() or 1
+    sample_len = min(256_000_000, max(16, cores) * 1_000_000)
     fa = os.path.join(workdir, "cpu_sample.fa")
     synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
     cfg = os.path.join(workdir, "cpu_config.txt")
@@ -75,16 +85,16 @@ def cpu_baseline(workdir, cores, profile="Illumina_HiSeqXTen.profile"):
     pairs = lines // 4
     for fn in os.listdir(out):
         os.remove(os.path.join(out, fn))
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": kind,
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "host_cores": f"{cores} of {cores}", "kind": kind,
             "sample": f"{sample_len} bp contig, {profile[9:-8]} PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
-                      f"(whole run incl. input load, threads={cores})"}
+                      f"(whole run incl. input load and FASTQ files, threads={cores})"}
 
 
-def pmc_traffic(pairs_per_step):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*/pmc_summary.json; FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same bench).  gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request
-    for wide coalesced reads -> doubled; both counters are in KiB."""
+def pmc_evidence():
+    """Per-launch counters of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/*/pmc_summary.json; FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same
+    bench).  gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request for wide
+    coalesced reads -> doubled; both counters are in KiB."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
@@ -96,38 +106,70 @@ def pmc_traffic(pairs_per_step):
             if "emit_fast_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 best = (path, v)
     if not best:
-        return None, None
-    path, v = best
-    traffic = (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-    return traffic, os.path.relpath(path, ROOT)
-
-
-def valu_evidence():
-    """The kernel is integer-VALU bound, not HBM bound: VALU issue utilisation of emit_fast_kernel from the
-    committed SQ counter pass (wave-instructions x 4 cycles on a 16-lane SIMD, v_mad_u64_u32 counted once
-    although it issues over 8) against 1024 SIMDs x the kernel's cycles at 2.4 GHz."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        stats = os.path.join(os.path.dirname(path), "kernel_stats.csv")
-        for k, v in d.items():
-            if "emit_fast_kernel" in k and "SQ_INSTS_VALU" in v and os.path.exists(stats):
-                ns = None
-                for line in open(stats):
-                    if "emit_fast_kernel" in line:
-                        ns = float(line.rsplit('",', 1)[1].split(",")[2]) if '",' in line else None
-                if ns:
-                    best = (path, v["SQ_INSTS_VALU"]["mean_per_dispatch"], ns)
-    if not best:
         return None
-    path, valu, ns = best
-    return {"bound": "integer VALU issue", "valu_wave_instructions_per_launch": valu,
-            "valu_issue_utilisation": valu * 4.0 / (1024 * ns * 2.4), "kernel_ns_rocprof": ns,
-            "source": os.path.relpath(os.path.dirname(path), ROOT)}
+    path, v = best
+    out = {"source": os.path.relpath(path, ROOT),
+           "traffic": (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0}
+    if "SQ_INSTS_VALU" in v:
+        out["valu"] = v["SQ_INSTS_VALU"]["mean_per_dispatch"]
+    return out
+
+
+def host_pinned_rate(sess, steps, gzip):
+    """SURVEY 8(d) metric: pairs whose FASTQ text is complete in pinned host memory.  Each pass's text leaves the
+    context as a detached output set and drains over PCIe (64 MB pinned buffers, two per mate) on a worker thread
+    while the next pass is sampled (and compressed) on the main stream."""
+    CH = 64 << 20
+    bufs = [sess.host_alloc(CH) for _ in range(4)]
+    moved = [0]
+
+    def drain(h):
+        text, gz = sess.outputs_sizes(h)
+        sizes = gz if gzip else text
+        for mate in (0, 1):
+            k = 0
+            for off in range(0, sizes[mate], CH):
+                n = min(CH, sizes[mate] - off)
+                sess.outputs_fetch_into(h, mate, gzip, off, n, bufs[2 * mate + (k & 1)])
+                moved[0] += n
+                k += 1
+
+    pending = None
+    pairs = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sess.sample()
+        _, _, nf = sess.result()
+        if gzip:
+            sess.compress()
+        h = sess.detach_outputs()
+        if pending:
+            pending[0].join()
+            sess.release_outputs(pending[1])
+        th = threading.Thread(target=drain, args=(h,))
+        th.start()
+        pending = (th, h)
+        pairs += nf
+    pending[0].join()
+    sess.release_outputs(pending[1])
+    dt = time.perf_counter() - t0
+    for b in bufs:
+        sess.host_free(b)
+    return {"value": pairs / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "pcie_GBps": moved[0] / dt / 1e9, "bytes_per_step": moved[0] / steps}
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun and relay its
+    output.  Nothing here has touched the GPU yet (no torch import, no engine): the child processes do."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    sys.exit(r.returncode)
 
 
 def main():
@@ -135,20 +177,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--scale", type=float, default=1.0, help="c3: contig lengths = GRCh38 primary lengths x scale")
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-pinned", action="store_true", help="skip the pinned-host legs (plain + gzip) after the timed region")
+    ap.add_argument("--no-md5", action="store_true")
     ap.add_argument("--profile", default="xten", choices=sorted(PROFILES),
                     help="sequencing profile of the workload (default: HiSeqXTen, the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.workload == "c3":
+        import bench_c3
+        return bench_c3.main(args)
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     if os.environ.get("BENCH_SAME_DEVICE"):   # rehearsal on a 1-GPU box: every rank on device 0 (gloo only)
@@ -240,6 +294,15 @@ def main():
         total_items = 2.0 * pairs_per_step * ((L + 7) // 8)
         main_share = 1.0 - queued_items / max(total_items, 1.0)
         achieved = pairs_per_step * bytes_per_pair * main_share / (emit_ms * 1e-3) / 1e9
+        pmc = pmc_evidence() if default_workload else None
+        compute_side = None
+        if pmc and "valu" in pmc:
+            # VALU issue occupancy of the LIVE launch: wave-instructions of the committed counter pass (the count does not
+            # depend on the run) x the microbenchmarked cycles per instruction, over 1024 SIMDs x this run's kernel time
+            compute_side = {"bound": "integer VALU issue", "valu_wave_instructions_per_launch": pmc["valu"],
+                            "cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION, "cost_model": "tools/valu_microbench.hip",
+                            "valu_issue_occupancy": pmc["valu"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * emit_ms * 1e-3 * 2.4e9),
+                            "clock_GHz_assumed": 2.4, "source": pmc["source"]}
         out = {
             "metric": "simulated paired reads/sec (whole node) at 30x WGS PE150",
             "value": total_pairs / dt_max,
@@ -256,23 +319,36 @@ def main():
             "config": {"workload": f"C2: one {args.contig_len} bp contig per GPU" + (" (GRCh38 chr20 length)" if args.contig_len == CHR20_LEN else "") + f", {PROFILES[args.profile][0][:-8]} profile "
                                    f"({L} bp), PE, {args.coverage}x, insertSize 350",
                        "pairs_per_step_per_gpu": pairs_per_step, "parallelism": f"{world} x 1 chromosome shard"},
+            "value_counts": "pairs whose FASTQ text is complete in HBM (inputs resident); the pinned-host rates are in host_pinned",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
                          # PMC traffic was collected on the default workload only
-                         "traffic": pmc_traffic(pairs_per_step)[0] if default_workload else None,
+                         "traffic": pmc["traffic"] if pmc else None,
                          "traffic_unit": "bytes per launch",
-                         "traffic_source": pmc_traffic(pairs_per_step)[1] if default_workload else None,
+                         "traffic_source": pmc["source"] if pmc else None,
                          "algorithmic_bytes_per_launch": pairs_per_step * bytes_per_pair * main_share,
                          "kernel": "emit_fast_kernel", "kernel_ms": emit_ms,
                          "items_left_to_emit_slow_kernel": 1.0 - main_share, "emit_slow_kernel_ms": slow_ms,
-                         "compute_side": valu_evidence(),
+                         "compute_side": compute_side,
                          "algorithmic_bytes_per_pair": bytes_per_pair, "bytes_note": BYTES_PER_PAIR_FMT},
             "kernel_ms_per_step": {k: v / args.steps for k, v in kms.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
+        if not args.no_md5:
+            out["output_md5"] = sess.output_md5()   # of the last timed pass (tests/test_gpu_full_size.py checks it against the oracle)
+            out["output_seed"] = 0x5EED0000 + rank
+        if world == 1 and not args.no_host_pinned:
             try:
-                out["cpu_baseline"] = cpu_baseline(workdir, cores, PROFILES[args.profile][0])
+                hs = max(2, min(args.steps, 4))
+                out["host_pinned"] = {"plain": host_pinned_rate(sess, hs, False), "gzip": host_pinned_rate(sess, hs, True),
+                                      "counts": "pairs whose FASTQ text (plain, or BGZF made on the device) is complete in pinned host "
+                                                "memory, passes drained while the next one is sampled",
+                                      "bound": "PCIe Gen5 x16, 63 GB/s (spec)"}
+            except Exception as e:
+                out["host_pinned"] = None
+                out["host_pinned_error"] = repr(e)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(workdir, PROFILES[args.profile][0])
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)

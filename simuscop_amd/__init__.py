@@ -74,7 +74,12 @@ class SgHapPatch(C.Structure):
 class SimuOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("has_seed", C.c_int32), ("seed", C.c_uint64), ("write_files", C.c_int32),
                 ("fetch", C.c_int32), ("quiet", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32), ("gzip", C.c_int32)]
+                ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32), ("gzip", C.c_int32),
+                ("shard_contigs", C.c_int32), ("no_eof_block", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
+
+
+# simu_options.exchange: all-reduce(sum) of n doubles over the ranks, in place
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 
 
 class SimuStats(C.Structure):
@@ -165,6 +170,8 @@ def load_host():
     vp = C.c_void_p
     lib.simu_default_options.argtypes = [C.POINTER(SimuOptions)]
     lib.simu_default_options.restype = None
+    lib.simu_assign_contigs.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.simu_assign_contigs.restype = None
     lib.simu_run.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(SimuStats), C.c_char_p, C.c_size_t]
     lib.simu_selftest_haplotypes.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t]
     lib.simu_open.argtypes = [C.c_char_p, C.POINTER(SimuOptions), C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -196,6 +203,8 @@ def default_options(**kw) -> SimuOptions:
             o.has_seed, o.seed = 1, int(v)
         elif k == "output_dir":
             o.output_dir = v.encode() if isinstance(v, str) else v
+        elif k == "exchange":
+            o.exchange = C.cast(v, C.c_void_p).value   # an EXCHANGE_FN instance; the caller keeps it alive
         else:
             setattr(o, k, v)
     return o
@@ -297,6 +306,50 @@ class Session:
         b2 = C.create_string_buffer(max(n2, 1))
         self._sg(self.eng.sg_fetch(self.ctx, b1, b2 if n2 else None), "sg_fetch")
         return b1.raw[:n1], b2.raw[:n2]
+
+    def output_md5(self, chunk: int = 1 << 27):
+        """md5 of each mate's whole FASTQ text of the last pass, fetched from the device in chunks."""
+        import hashlib
+        b1, b2, _ = self.result()
+        out = []
+        buf = C.create_string_buffer(chunk)
+        for mate, total in ((0, b1), (1, b2)):
+            if mate == 1 and not total:
+                break
+            h = hashlib.md5()
+            for off in range(0, total, chunk):
+                n = min(chunk, total - off)
+                self._sg(self.eng.sg_fetch_range(self.ctx, mate, off, n, buf), "sg_fetch_range")
+                h.update(memoryview(buf)[:n])
+            out.append(h.hexdigest())
+        return out
+
+    # ---- detached output sets: the text of a pass drains to pinned host memory while the next pass is sampled ----
+    def host_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._sg(self.eng.sg_host_alloc(self.ctx, nbytes, C.byref(p)), "sg_host_alloc")
+        return p.value
+
+    def host_free(self, ptr: int) -> None:
+        self._sg(self.eng.sg_host_free(self.ctx, C.c_void_p(ptr)), "sg_host_free")
+
+    def detach_outputs(self):
+        h = C.c_void_p()
+        self._sg(self.eng.sg_detach_outputs(self.ctx, C.byref(h)), "sg_detach_outputs")
+        return h
+
+    def outputs_sizes(self, h):
+        tb, gb = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        self.eng.sg_outputs_sizes(h, tb, gb)
+        return (tb[0], tb[1]), (gb[0], gb[1])
+
+    def outputs_fetch_into(self, h, mate: int, compressed: bool, offset: int, nbytes: int, host_ptr: int) -> None:
+        rc = self.eng.sg_outputs_fetch(h, mate, 1 if compressed else 0, offset, nbytes, C.cast(C.c_void_p(host_ptr), C.c_char_p))
+        if rc != 0:
+            raise SimuError("sg_outputs_fetch: " + self.eng.sg_outputs_last_error(h).decode(errors="replace"))
+
+    def release_outputs(self, h) -> None:
+        self._sg(self.eng.sg_release_outputs(self.ctx, h), "sg_release_outputs")
 
     def stats(self) -> SimuStats:
         st = SimuStats()

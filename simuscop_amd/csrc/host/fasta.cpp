@@ -79,6 +79,69 @@ std::string pread_string(int fd, uint64_t off, uint64_t n) {
   s.resize((size_t)have);
   return s;
 }
+
+// Index rows (what a .fai line holds) of the contigs whose header lines start at the sorted file offsets `hdr`:
+// a few small preads per contig -- header text, first line (bases / bytes per line), last bytes.  False when a
+// contig's body cannot be a run of equal-width lines.
+bool rows_from_headers(int fd, uint64_t size, const std::vector<uint64_t>& hdr, std::vector<std::string>& keys,
+                       std::vector<FastaContig>& rows) {
+  for (size_t i = 0; i < hdr.size(); i++) {
+    const uint64_t region_end = i + 1 < hdr.size() ? hdr[i + 1] : size;
+    // header line
+    std::string head;
+    uint64_t p = hdr[i] + 1, first = region_end;
+    for (;;) {
+      const std::string blk = pread_string(fd, p, std::min<uint64_t>(4096, region_end - p));
+      if (blk.empty()) break;
+      const size_t nl = blk.find('\n');
+      if (nl != std::string::npos) { head.append(blk, 0, nl); first = p + nl + 1; break; }
+      head += blk;
+      p += blk.size();
+    }
+    FastaContig row;
+    row.raw_offset = first;
+    // trailing line breaks (and blank lines) of the region do not belong to a line
+    uint64_t end = region_end;
+    while (end > first) {
+      const uint64_t n = std::min<uint64_t>(64, end - first);
+      const std::string tail = pread_string(fd, end - n, n);
+      size_t k = tail.size();
+      while (k > 0 && (tail[k - 1] == '\n' || tail[k - 1] == '\r')) k--;
+      end -= tail.size() - k;
+      if (k > 0) break;
+    }
+    const uint64_t body = end - first;
+    if (body) {
+      // first line: bases per line, bytes per line
+      uint64_t q = first, lb = body, lw = body;
+      bool found_nl = false;
+      while (q < end && !found_nl) {
+        const std::string blk = pread_string(fd, q, std::min<uint64_t>(1u << 16, end - q));
+        if (blk.empty()) break;
+        const size_t nl = blk.find('\n');
+        if (nl != std::string::npos) {
+          const uint64_t at = q + nl;  // file offset of the '\n'
+          const bool cr = at > first && (nl > 0 ? blk[nl - 1] == '\r' : pread_string(fd, at - 1, 1) == "\r");
+          lb = at - first - (cr ? 1 : 0);
+          lw = at - first + 1;
+          found_nl = true;
+        }
+        q += blk.size();
+      }
+      if (lb == 0 || lb > 0xFFFFFFF0ull || lw > 0xFFFFFFF0ull) return false;
+      const uint64_t k = body / lw, r = body % lw;
+      if (r > lb) return false;
+      row.length = k * lb + r;
+      row.line_bases = (uint32_t)lb;
+      row.line_width = (uint32_t)lw;
+    } else {
+      row.line_bases = row.line_width = 1;
+    }
+    keys.push_back(header_key(head));
+    rows.push_back(row);
+  }
+  return true;
+}
 }  // namespace
 
 void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads) {
@@ -120,61 +183,7 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
     bool uniform = !(flags & 1u) && found > 0;
     std::vector<std::string> keys;
     std::vector<FastaContig> rows;
-    for (size_t i = 0; i < hdr.size() && uniform; i++) {
-      const uint64_t region_end = i + 1 < hdr.size() ? hdr[i + 1] : size;
-      // header line
-      std::string head;
-      uint64_t p = hdr[i] + 1, first = region_end;
-      for (;;) {
-        const std::string blk = pread_string(fd, p, std::min<uint64_t>(4096, region_end - p));
-        if (blk.empty()) break;
-        const size_t nl = blk.find('\n');
-        if (nl != std::string::npos) { head.append(blk, 0, nl); first = p + nl + 1; break; }
-        head += blk;
-        p += blk.size();
-      }
-      FastaContig row;
-      row.raw_offset = first;
-      // trailing line breaks (and blank lines) of the region do not belong to a line
-      uint64_t end = region_end;
-      while (end > first) {
-        const uint64_t n = std::min<uint64_t>(64, end - first);
-        const std::string tail = pread_string(fd, end - n, n);
-        size_t k = tail.size();
-        while (k > 0 && (tail[k - 1] == '\n' || tail[k - 1] == '\r')) k--;
-        end -= tail.size() - k;
-        if (k > 0) break;
-      }
-      const uint64_t body = end - first;
-      if (body) {
-        // first line: bases per line, bytes per line
-        uint64_t q = first, lb = body, lw = body;
-        bool found_nl = false;
-        while (q < end && !found_nl) {
-          const std::string blk = pread_string(fd, q, std::min<uint64_t>(1u << 16, end - q));
-          if (blk.empty()) break;
-          const size_t nl = blk.find('\n');
-          if (nl != std::string::npos) {
-            const uint64_t at = q + nl;  // file offset of the '\n'
-            const bool cr = at > first && (nl > 0 ? blk[nl - 1] == '\r' : pread_string(fd, at - 1, 1) == "\r");
-            lb = at - first - (cr ? 1 : 0);
-            lw = at - first + 1;
-            found_nl = true;
-          }
-          q += blk.size();
-        }
-        if (lb == 0 || lb > 0xFFFFFFF0ull || lw > 0xFFFFFFF0ull) { uniform = false; break; }
-        const uint64_t k = body / lw, r = body % lw;
-        if (r > lb) { uniform = false; break; }
-        row.length = k * lb + r;
-        row.line_bases = (uint32_t)lb;
-        row.line_width = (uint32_t)lw;
-      } else {
-        row.line_bases = row.line_width = 1;
-      }
-      keys.push_back(header_key(head));
-      rows.push_back(row);
-    }
+    if (uniform) uniform = rows_from_headers(fd, size, hdr, keys, rows);
     if (uniform) {
       std::vector<sg_contig> tab;
       for (const FastaContig& r : rows) tab.push_back(sg_contig{r.raw_offset, r.length, r.line_bases, r.line_width});
@@ -290,6 +299,134 @@ void Fasta::open(const std::string& ref_file) {
     row.length = seqs.at(k).size();
     contigs.push_back(row);
   }
+}
+
+// ---- sharded ingest -------------------------------------------------------------------------------------
+bool Fasta::load_index(const std::string& ref_file, int threads) {
+  const std::string path = plain_path(ref_file);
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw Error("could not open " + path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { ::close(fd); throw Error("could not open " + path); }
+  const uint64_t size = (uint64_t)sb.st_size;
+  std::vector<std::string> keys;
+  std::vector<FastaContig> rows;
+  bool ok = false;
+  // 1. a .fai next to the file: NAME LENGTH OFFSET LINEBASES LINEWIDTH (Fasta.cpp:45-85)
+  struct stat ib;
+  const std::string fai = path + ".fai";
+  if (stat(fai.c_str(), &ib) == 0 && ib.st_mtime >= sb.st_mtime) {
+    if (FILE* f = fopen(fai.c_str(), "r")) {
+      char line[4096];
+      ok = true;
+      while (fgets(line, sizeof line, f)) {
+        char name[2048];
+        unsigned long long len, off, lb, lw;
+        if (sscanf(line, "%2047s %llu %llu %llu %llu", name, &len, &off, &lb, &lw) != 5 || lb == 0 || lw < lb) { ok = false; break; }
+        FastaContig r;
+        r.length = len; r.raw_offset = off; r.line_bases = (uint32_t)lb; r.line_width = (uint32_t)lw;
+        if (off + len + (len ? (len - 1) / lb : 0) * (lw - lb) > size) { ok = false; break; }
+        keys.push_back(abbr_of_chr(name));
+        rows.push_back(r);
+      }
+      fclose(f);
+      if (rows.empty()) ok = false;
+      if (!ok) { keys.clear(); rows.clear(); }
+    }
+  }
+  // 2. header scan on the host: '>' at a line start; '@' headers and ';' comment lines are left to the general parser
+  if (!ok) {
+    const int nt = std::max(1, threads);
+    const uint64_t kChunk = 8u << 20;
+    const uint64_t nchunks = (size + kChunk - 1) / kChunk;
+    std::vector<std::vector<uint64_t>> found((size_t)nt);
+    std::vector<char> odd((size_t)nt, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++)
+      pool.emplace_back([&, t]() {
+        std::vector<char> buf(kChunk + 1);
+        for (uint64_t c = (uint64_t)t; c < nchunks; c += (uint64_t)nt) {
+          // one byte of lead-in: the line-start test of the chunk's first byte
+          const uint64_t a = c * kChunk, lead = a ? 1 : 0, n = std::min<uint64_t>(kChunk, size - a);
+          uint64_t have = 0;
+          while (have < n + lead) {
+            const ssize_t got = pread(fd, buf.data() + have, n + lead - have, (off_t)(a - lead + have));
+            if (got <= 0) { odd[(size_t)t] = 1; return; }
+            have += (uint64_t)got;
+          }
+          const char* p0 = buf.data() + lead;
+          for (const char* p = p0; p < p0 + n;) {
+            const bool at_start = (p == p0) ? (a == 0 || p[-1] == '\n') : true;
+            if (at_start) {
+              if (*p == '>') found[(size_t)t].push_back(a + (uint64_t)(p - p0));
+              else if (*p == '@' || *p == ';') odd[(size_t)t] = 1;
+            }
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(p0 + n - p));
+            if (!nl) break;
+            p = nl + 1;
+          }
+        }
+      });
+    for (std::thread& th : pool) th.join();
+    std::vector<uint64_t> hdr;
+    bool plain = true;
+    for (int t = 0; t < nt; t++) { plain &= !odd[(size_t)t]; hdr.insert(hdr.end(), found[(size_t)t].begin(), found[(size_t)t].end()); }
+    std::sort(hdr.begin(), hdr.end());
+    ok = plain && !hdr.empty() && rows_from_headers(fd, size, hdr, keys, rows);
+  }
+  ::close(fd);
+  if (!ok) return false;
+  on_device = true;
+  names.clear(); seqs.clear(); contigs = rows; contig_of.clear(); dev_row.clear();
+  for (size_t i = 0; i < keys.size(); i++) {  // a repeated name keeps its first place and its last sequence
+    if (!contig_of.count(keys[i])) names.push_back(keys[i]);
+    contig_of[keys[i]] = (uint32_t)i;
+  }
+  return true;
+}
+
+void Fasta::open_owned_on_device(const std::string& ref_file, sg_ctx* ctx, int threads, const std::vector<char>& owned) {
+  const std::string path = plain_path(ref_file);
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw Error("could not open " + path);
+  // device image: the owned contigs' line ranges back to back (64-byte aligned starts)
+  struct Piece { uint64_t file_off, bytes, dev_off; };
+  std::vector<Piece> pieces;
+  std::vector<sg_contig> tab;
+  dev_row.assign(contigs.size(), -1);
+  uint64_t total = 0;
+  for (size_t i = 0; i < contigs.size(); i++) {
+    if (i >= owned.size() || !owned[i]) continue;
+    const FastaContig& r = contigs[i];
+    const uint64_t bytes = r.length + (r.length ? (r.length - 1) / r.line_bases : 0) * (uint64_t)(r.line_width - r.line_bases);
+    dev_row[i] = (int32_t)tab.size();
+    tab.push_back(sg_contig{total, r.length, r.line_bases, r.line_width});
+    pieces.push_back(Piece{r.raw_offset, bytes, total});
+    total += (bytes + 63) & ~(uint64_t)63;
+  }
+  void* stage[2] = {nullptr, nullptr};
+  try {
+    eng_check(ctx, sg_reference_begin(ctx, total), "sg_reference_begin");
+    const uint64_t kChunk = 64u << 20;
+    for (int i = 0; i < 2 && total; i++) eng_check(ctx, sg_host_alloc(ctx, std::min<uint64_t>(kChunk, total), &stage[i]), "sg_host_alloc");
+    int cur = 0;
+    for (const Piece& pc : pieces)
+      for (uint64_t off = 0; off < pc.bytes; off += kChunk, cur ^= 1) {
+        const uint64_t n = std::min<uint64_t>(kChunk, pc.bytes - off);
+        parallel_pread(fd, (uint8_t*)stage[cur], pc.file_off + off, n, threads);  // overlaps the copy of the other buffer
+        eng_check(ctx, sg_sync(ctx), "sg_sync");
+        eng_check(ctx, sg_reference_chunk(ctx, pc.dev_off + off, stage[cur], n), "sg_reference_chunk");
+      }
+    eng_check(ctx, sg_sync(ctx), "sg_sync");
+    eng_check(ctx, sg_reference_commit(ctx, tab.data(), (uint32_t)tab.size()), "sg_reference_commit");
+  } catch (...) {
+    ::close(fd);
+    for (void* b : stage) if (b) sg_host_free(ctx, b);
+    throw;
+  }
+  ::close(fd);
+  for (void* b : stage) if (b) sg_host_free(ctx, b);
+  streamed = true;
 }
 
 }  // namespace simu

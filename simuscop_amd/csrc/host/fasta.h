@@ -28,12 +28,26 @@ struct Fasta {
   std::vector<FastaContig> contigs;          // order of the table given to sg_reference_commit
   std::map<std::string, uint32_t> contig_of; // key -> row of `contigs`
   bool streamed = false;                     // false: the general host parser ran and its result was uploaded
+  // sharded ingest (multi-GPU, ranks own whole contigs): every contig is in `names` / `contigs` with its length,
+  // but only the owned ones are on this device; dev_row = row of the table given to sg_reference_commit, or -1
+  std::vector<int32_t> dev_row;
 
   void open(const std::string& path);        // handles the reference's `.gz` convention (Genome.cpp:224-228)
   // Streams the file to the engine (`threads` readers, two pinned staging buffers), finds the headers
   // with the device scan, reads only the header lines on the host.  Files the arithmetic ingest cannot
   // take (lines of several widths, ';' comments) go through open() and are uploaded stripped.
   void open_on_device(const std::string& path, ::sg_ctx* ctx, int threads);
+  // The file's index rows without loading it: from `<path>.fai` when that is at least as new as the file
+  // (the reference keeps such an index next to the FASTA, lib/fastahack/Fasta.cpp:45-85, 233-260), else from a
+  // header scan on `threads` host threads.  False (nothing changed) when the file is not a plain fixed-width FASTA.
+  bool load_index(const std::string& path, int threads);
+  // Sharded ingest: after load_index(), stream ONLY the contigs with owned[row] != 0 to the engine.
+  void open_owned_on_device(const std::string& path, ::sg_ctx* ctx, int threads, const std::vector<char>& owned);
+  int32_t device_row(const std::string& chr) const {
+    auto it = contig_of.find(chr);
+    if (it == contig_of.end()) return -1;
+    return dev_row.empty() ? (int32_t)it->second : dev_row[it->second];
+  }
   long length(const std::string& chr) const {
     if (on_device) {
       auto it = contig_of.find(chr);

@@ -259,7 +259,9 @@ void Genome::segment_haplotypes(const std::string& popu, const std::string& chr,
 // carried through the table at the end.
 void Genome::segment_pieces(const std::string& popu, const std::string& chr, Segment& g, ChromPlan& plan) {
   const int ploidy = cfg.ploidy();
-  const uint32_t contig = fa.contig_of.at(chr);
+  const int32_t dev_contig = fa.device_row(chr);
+  if (dev_contig < 0) throw Error("ERROR: chromosome " + chr + " is not resident on this device");
+  const uint32_t contig = (uint32_t)dev_contig;
   // contig.substr(start-1, ref_size) clips at the contig end
   const unsigned ref_size = (unsigned)std::min<long>((long)g.ref_size(), fa.length(chr) - (g.start - 1));
   struct Piece { uint32_t kind; uint64_t src; uint64_t len; };

@@ -10,6 +10,7 @@
 //   * haplotypes are built ONCE per (population, chromosome) and kept, instead of twice per run
 //     (Genome.cpp:793 via getWeightedLength, then :876-878).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -83,6 +84,19 @@ struct Genome {
   bool device_haps = false;
   ::sg_ctx* engine = nullptr;
   double t_reference = 0;  // seconds spent in Fasta::open / open_on_device
+  // Multi-GPU, ranks own whole chromosomes: owner[i] = rank of chromosomes[i] (empty: all here).  Only
+  // the owned contigs are ingested, cut into haplotype chains, scanned and sampled by this process.
+  int shard_rank = 0, shard_world = 1;
+  bool shard_contigs = false;
+  std::vector<int> owner;
+  bool owns(const std::string& chr) const {
+    if (owner.empty()) return true;
+    const size_t i = (size_t)(std::find(chromosomes.begin(), chromosomes.end(), chr) - chromosomes.begin());
+    return i < owner.size() && owner[i] == shard_rank;
+  }
+  // Longest-first greedy assignment of contigs to `world` ranks by length (ties: file order, lowest rank): the read
+  // count of a chromosome follows its GC-weighted length, which follows its length.
+  static std::vector<int> assign_contigs(const std::vector<uint64_t>& lengths, int world);
 
   explicit Genome(Config& c) : cfg(c) {}
 

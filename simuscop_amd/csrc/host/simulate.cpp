@@ -43,7 +43,7 @@ struct Engine {  // RAII around sg_ctx, turns status codes into simu::Error
 struct Sink {  // FASTQ output: <output>/<stem>_1.fq + _2.fq, or <stem>.fq (Genome.cpp:857-866)
   FILE* f1 = nullptr;
   FILE* f2 = nullptr;
-  bool bgzf = false;
+  bool bgzf = false, eof_block = true;
   void open(const std::string& dir, const std::string& stem, bool paired, const std::string& suffix0, bool gz = false) {
     close();
     bgzf = gz;
@@ -61,7 +61,7 @@ struct Sink {  // FASTQ output: <output>/<stem>_1.fq + _2.fq, or <stem>.fq (Geno
     }
   }
   void close() {
-    if (bgzf) {  // BGZF end-of-file marker
+    if (bgzf && eof_block) {  // BGZF end-of-file marker
       uint8_t eof[28];
       sg_bgzf_eof(eof);
       if (f1) fwrite(eof, 1, 28, f1);
@@ -89,9 +89,11 @@ struct Driver {
   std::vector<uint32_t> seg_size, seg_first;
   std::vector<sg_gc_window> gcw;
   std::vector<int32_t> gcv;
+  Sink sink;  // a member, so that an error path joins the drain in flight (below) before the files are closed
 
   ~Driver() {
     if (pending.active && pending.th.joinable()) pending.th.join();
+    if (pending.active && pending.handle && eng.ctx) sg_release_outputs(eng.ctx, pending.handle);
     for (void* b : pinned)
       if (b && eng.ctx) sg_host_free(eng.ctx, b);
   }
@@ -186,7 +188,7 @@ struct Driver {
   void prebuild(const std::string& popu) {
     std::vector<std::string> todo;
     for (const std::string& chr : genome.chromosomes)
-      if (!genome.plans[popu][chr].chains_built) todo.push_back(chr);
+      if (genome.owns(chr) && !genome.plans[popu][chr].chains_built) todo.push_back(chr);
     const size_t nthreads = std::min<size_t>((size_t)std::max<long long>(1, cfg.num["threads"]), todo.size());
     if (nthreads <= 1) return;  // weigh() builds on demand
     auto t0 = Clock::now();
@@ -215,18 +217,30 @@ struct Driver {
   }
 
   // Genome::setReadCounts, Genome.cpp:783-825
+  std::map<std::string, std::vector<double>> chr_wl_of;  // per population: GC-weighted length of every chromosome
   void set_read_counts(const std::string& popu, long reads) {
     prebuild(popu);
-    std::vector<double> chr_wl;
-    double WL = 0;
-    for (const std::string& chr : genome.chromosomes) {
-      weigh(popu, chr);
-      ChromPlan& plan = genome.plans[popu][chr];
-      double c = 0;
-      for (const Segment& g : plan.segs) c += seg_weight(plan, g);
-      WL += c;
-      chr_wl.push_back(c);
+    std::vector<double>& chr_wl = chr_wl_of[popu];
+    if (chr_wl.empty()) {
+      for (const std::string& chr : genome.chromosomes) {
+        double c = 0;
+        if (genome.owns(chr)) {
+          weigh(popu, chr);
+          ChromPlan& plan = genome.plans[popu][chr];
+          for (const Segment& g : plan.segs) c += seg_weight(plan, g);
+        }
+        chr_wl.push_back(c);
+      }
+      if (!genome.owner.empty()) {
+        // the other ranks' chromosomes: one small exchange per population (RCCL / gloo all-reduce in the torchrun front
+        // end, the parent's pipes under `simuReads --gpus N`); each entry has one owner, so the sum is exact
+        if (!opt.exchange) throw Error("ERROR: chromosome sharding needs an exchange callback (simu_options.exchange)");
+        if (opt.exchange(opt.exchange_user, chr_wl.data(), (int32_t)chr_wl.size()) != 0)
+          throw Error("ERROR: the weighted-length exchange between the ranks failed");
+      }
     }
+    double WL = 0;
+    for (double c : chr_wl) WL += c;
     auto t0 = Clock::now();
     long cur = 0;
     for (size_t i = 0; i < genome.chromosomes.size(); i++) {
@@ -234,7 +248,7 @@ struct Driver {
       const double cw = chr_wl[i];
       const long chr_reads = i + 1 < genome.chromosomes.size() ? (long)(reads * (cw / WL)) : reads - cur;
       long sum = 0;
-      for (size_t j = 0; j < plan.segs.size(); j++) {
+      for (size_t j = 0; genome.owns(genome.chromosomes[i]) && j < plan.segs.size(); j++) {
         Segment& g = plan.segs[j];
         if (j + 1 < plan.segs.size()) {
           const double share = seg_weight(plan, g) / cw;
@@ -271,8 +285,9 @@ struct Driver {
     ChromPlan& plan = genome.plans[popu][chr];
     cur = BatchPlan();
     cur.popu = popu; cur.chr = chr;
-    cur.bid = batch_id++;
+    cur.bid = batch_id++;  // every rank numbers every batch alike: the id addresses the draws
     if (cur.bid > 0xFFFF) throw Error("ERROR: more than 65535 (population, chromosome) batches");
+    if (!genome.owns(chr)) return false;
     st.batches++;
     const bool paired = cur.paired = cfg.paired();
     cur.prefix = "@" + popu + "#" + chr + "#";
@@ -314,7 +329,7 @@ struct Driver {
 
     // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
     cur.a0 = 0; cur.a1 = act.size();
-    if (opt.shard_world > 1) {
+    if (opt.shard_world > 1 && !opt.shard_contigs) {
       const uint64_t per = (slot + opt.shard_world - 1) / opt.shard_world;
       uint64_t acc = 0;
       cur.a0 = cur.a1 = act.size();
@@ -544,11 +559,16 @@ struct Driver {
     st.t_engine = since(t1);
     genome.device_haps = !opt.host_haplotypes;
     genome.engine = eng.ctx;
+    genome.shard_rank = opt.shard_rank;
+    genome.shard_world = opt.shard_world;
+    genome.shard_contigs = opt.shard_contigs != 0 && opt.shard_world > 1;
     genome.load_data();
     st.t_reference = genome.t_reference;
     const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
-    if (opt.write_files) mkdir(out_dir.c_str(), 0755);  // src/simuReads.cpp:56-60
-    (void)out_dir;
+    if (opt.write_files) {  // `mkdir -p` (src/simuReads.cpp:56-60)
+      for (size_t i = 1; i <= out_dir.size(); i++)
+        if (i == out_dir.size() || out_dir[i] == '/') mkdir(out_dir.substr(0, i).c_str(), 0755);
+    }
     prof.train(cfg.str["profile"], cfg.paired(), (int)cfg.num["insertSize"]);
     log("profile was loaded from file " + cfg.str["profile"] + "\n");
     sg_profile_cdf view = prof.view();
@@ -575,7 +595,7 @@ struct Driver {
     log("\n*****Generating samples*****\n");
     const bool paired = cfg.paired();
     const std::string suffix = opt.shard_world > 1 ? ".part" + std::to_string(opt.shard_rank) : "";
-    Sink sink;
+    sink.eof_block = !opt.no_eof_block;
     if (genome.mix_props.empty()) {
       if (opt.write_files) sink.open(out_dir, popus[0], paired, suffix, opt.gzip != 0);
       set_read_counts(popus[0], reads);
@@ -614,6 +634,11 @@ extern "C" void simu_default_options(simu_options* o) {
   o->device = -1;
   o->write_files = 1;
   o->shard_world = 1;
+}
+
+extern "C" void simu_assign_contigs(const uint64_t* lengths, int32_t n, int32_t world, int32_t* owner_out) {
+  const std::vector<int> o = simu::Genome::assign_contigs(std::vector<uint64_t>(lengths, lengths + n), world);
+  for (int32_t i = 0; i < n; i++) owner_out[i] = o[(size_t)i];
 }
 
 extern "C" int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats, char* err, size_t err_len) {

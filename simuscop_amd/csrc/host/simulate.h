@@ -23,6 +23,15 @@ typedef struct simu_options {
                            // assemble the haplotypes there (sg_reference_*, sg_build_haplotypes)
   int32_t gzip;            // 1: compress the FASTQ text on the device (sg_compress) and write <name>_1.fq.gz ...
                            // as BGZF (block gzip); what `zcat` gives back is byte for byte the plain file
+  int32_t shard_contigs;   // multi-GPU, 1: rank shard_rank of shard_world OWNS whole chromosomes (longest-first assignment
+                           // by length): it ingests, cuts, scans and samples only those; the per-chromosome GC-weighted
+                           // lengths every rank needs for the read apportioning (Genome::setReadCounts) come through
+                           // `exchange`.  0: every rank holds the whole genome and samples its run of segments of every batch.
+  int32_t no_eof_block;    // gzip part files: leave the BGZF end-of-file block to whoever concatenates the parts
+  // all-reduce(sum) of n doubles over the ranks, in place; every element has exactly one non-zero contributor (its
+  // owner), so the sum is exact whatever the order.  Called once per population.  Returns 0 on success.
+  int (*exchange)(void* user, double* values, int32_t n);
+  void* exchange_user;
 } simu_options;
 
 typedef struct simu_stats {
@@ -54,6 +63,10 @@ typedef struct simu_stats {
 int simu_run(const char* config_path, const simu_options* opt, simu_stats* stats, char* err, size_t err_len);
 
 void simu_default_options(simu_options* opt);
+
+// Chromosome ownership of the shard_contigs mode: owner_out[i] = rank of contig i (longest first onto the least
+// loaded rank; ties by file order).  Exposed for the launchers and tests.
+void simu_assign_contigs(const uint64_t* lengths, int32_t n, int32_t world, int32_t* owner_out);
 
 // CPU-only self-test of the haplotype edit lists (no GPU call): every (population, chromosome) of the config is
 // built twice -- as strings (Genome::segment_haplotypes, the reference's std::string editing) and as the copy list

@@ -161,12 +161,46 @@ void Genome::load_abundance() {
   }
 }
 
+std::vector<int> Genome::assign_contigs(const std::vector<uint64_t>& lengths, int world) {
+  std::vector<size_t> order(lengths.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lengths[a] > lengths[b]; });
+  std::vector<uint64_t> load((size_t)std::max(1, world), 0);
+  std::vector<int> out(lengths.size(), 0);
+  for (size_t i : order) {
+    const size_t r = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+    out[i] = (int)r;
+    load[r] += lengths[i];
+  }
+  return out;
+}
+
 void Genome::load_data() {
   load_variations();
   load_snps();
   const auto t0 = std::chrono::steady_clock::now();
-  if (device_haps) fa.open_on_device(cfg.str["ref"], engine, (int)std::max<long long>(1, cfg.num["threads"]));
-  else fa.open(cfg.str["ref"]);
+  const int threads = (int)std::max<long long>(1, cfg.num["threads"]);
+  bool sharded_ingest = false;
+  if (device_haps && shard_contigs && shard_world > 1 && fa.load_index(cfg.str["ref"], threads)) {
+    // ranks own whole contigs: ingest only those (the index comes from the .fai or a host header scan)
+    std::vector<uint64_t> lens;
+    for (const std::string& k : fa.names) lens.push_back(fa.contigs[fa.contig_of.at(k)].length);
+    owner = assign_contigs(lens, shard_world);
+    std::vector<char> owned(fa.contigs.size(), 0);
+    for (size_t i = 0; i < fa.names.size(); i++)
+      if (owner[i] == shard_rank) owned[fa.contig_of.at(fa.names[i])] = 1;
+    fa.open_owned_on_device(cfg.str["ref"], engine, threads, owned);
+    sharded_ingest = true;
+  }
+  if (!sharded_ingest) {
+    if (device_haps) fa.open_on_device(cfg.str["ref"], engine, threads);
+    else fa.open(cfg.str["ref"]);
+    if (shard_contigs && shard_world > 1) {  // ingest replicated (host haplotypes, or not a plain FASTA): planning and sampling still sharded
+      std::vector<uint64_t> lens;
+      for (const std::string& k : fa.names) lens.push_back((uint64_t)fa.length(k));
+      owner = assign_contigs(lens, shard_world);
+    }
+  }
   t_reference = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   chromosomes = fa.names;
   load_targets();

@@ -47,3 +47,33 @@ def balance_reads(my_wl: float, my_target_len: int, coverage: int, read_length: 
     reads = total_len * coverage // read_length  # Genome.cpp:831
     per_chr = apportion(reads, wls)
     return per_chr[rank], reads
+
+
+def make_exchange(device=None):
+    """simu_options.exchange for the chromosome-sharded mode: an in-place all-reduce(sum) of the per-chromosome
+    weighted lengths over torch.distributed (RCCL when the backend is "nccl", gloo in the CPU tests).  Every entry has
+    exactly one non-zero contributor -- the rank that owns the chromosome -- so the sum is exact in any order.
+    Returns the ctypes callback (keep a reference to it while the run lasts)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import EXCHANGE_FN
+
+    def _exchange(_user, values, n):
+        try:
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                return 0
+            arr = np.ctypeslib.as_array(values, shape=(n,))
+            t = torch.from_numpy(arr.copy()).to(device) if device is not None else torch.from_numpy(arr.copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            arr[:] = t.cpu().numpy()
+            return 0
+        except Exception:   # a Python exception must not unwind through the C++ caller
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return EXCHANGE_FN(_exchange)

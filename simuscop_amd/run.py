@@ -3,8 +3,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m simuscop_amd.run config.txt [--seed N] [--no-write] [--merge]
 
-Every (population, chromosome) batch is split over the ranks by runs of segments balanced on planned
-fragments (host/simulate.cpp, `shard_rank/shard_world`).  Because every draw is addressed inside the
+Two ways to shard (host/simulate.cpp): by default every (population, chromosome) batch is split over the ranks
+by runs of segments balanced on planned fragments (`shard_rank/shard_world`; every rank holds the whole genome);
+with --shard-contigs the ranks OWN whole chromosomes (longest-first by length) and ingest, scan and sample only
+those -- the per-chromosome GC-weighted lengths of Genome::setReadCounts are all-reduced once per population.  Because every draw is addressed inside the
 whole batch, the ranks' part files `<name>_1.fq.part<r>` hold exactly the reads of the 1-GPU run
 (tests/test_gpu_parity.py::test_sharded_run_equals_unsharded).  No bulk data moves between GPUs:
 the collectives here are a barrier and an all_gather of per-rank statistics.  Each rank evaluates the
@@ -28,6 +30,9 @@ def main(argv=None):
     ap.add_argument("--no-write", action="store_true", help="keep results on the devices (throughput runs)")
     ap.add_argument("--merge", action="store_true", help="rank 0 concatenates the part files per output file")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--shard-contigs", action="store_true",
+                    help="ranks own whole chromosomes: each ingests, scans and samples only its own; the per-chromosome "
+                         "weighted lengths are exchanged with one all-reduce per population")
     args = ap.parse_args(argv)
 
     import torch
@@ -53,6 +58,12 @@ def main(argv=None):
                 write_files=0 if args.no_write else 1)
     if args.seed is not None:
         opts["seed"] = args.seed
+    exchange = None
+    if args.shard_contigs and world > 1:
+        from simuscop_amd import dist as sdist
+        exchange = sdist.make_exchange("cuda" if args.backend == "nccl" else None)
+        opts["shard_contigs"] = 1
+        opts["exchange"] = exchange
     t0 = time.time()
     st = simuscop_amd.run_config(args.config, **opts)
     dt = time.time() - t0

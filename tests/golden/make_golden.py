@@ -5,6 +5,9 @@ Needs /root/reference (this container only).  Builds oracle/_ref/simuReads (make
 g++ on the reference's own sources where they lie) and runs it on every case of tests/cases.py
 under oracle/fakeclock.c (frozen wall clock => frozen RNG seeds) with threads = 1.  Only md5 sums,
 sizes and read counts are kept (data, not source).
+
+    python tests/golden/make_golden.py [case ...]     named cases (default: every case of cases.CASES)
+    python tests/golden/make_golden.py --slow          also the full-coverage C3 / C4 cases (cases.SLOW_CASES: minutes each)
 """
 import hashlib
 import json
@@ -32,7 +35,9 @@ def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
     ref = os.path.join(ROOT, "oracle", "_ref", "simuReads")
     shim = os.path.join(ROOT, "oracle", "_ref", "libfakeclock.so")
-    only = sys.argv[1:] or list(cases.CASES)
+    only = [a for a in sys.argv[1:] if a != "--slow"] or list(cases.CASES)
+    if "--slow" in sys.argv:
+        only += [n for n in cases.SLOW_CASES if n not in only]
     path = os.path.join(HERE, "golden.json")
     golden = json.load(open(path)) if os.path.exists(path) else {}
     for name in only:

@@ -138,3 +138,31 @@ def test_cli_gpus_option_equals_one_gpu(tmp_path):
                 import gzip
                 blob = gzip.decompress(blob)
             assert sorted(_records(blob)) == sorted(_records(open(os.path.join(one, f), "rb").read())), (tag, f)
+
+
+@pytest.mark.parametrize("name", ["wgs_pe_variants", "c3_grch38_pe_xten_cov3", "c4_tumor_pe_xten_cov6"])
+def test_ranks_owning_whole_chromosomes(name, tmp_path):
+    """--shard-contigs: every rank ingests, scans and samples only the chromosomes it owns (the weighted lengths of the
+    others come through the exchange); the merged files hold exactly the records of the one-GPU run.  Through the CLI's
+    own process-per-GPU launcher (pipes to the parent) and through the torchrun front end (gloo all-reduce)."""
+    import sys
+    cfg = cases.build_case(name, str(tmp_path))
+    one = str(tmp_path / "one")
+    _run_gpu(cfg, one)
+    env = dict(os.environ, SIMUSCOP_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    d = str(tmp_path / "cli")
+    r = subprocess.run([SIMU, cfg, "--seed", str(SEED), "--out", d, "--quiet", "--gpus", "3", "--shard-contigs"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _files(d) == _files(one)
+    for f in _files(one):
+        assert sorted(_records(open(os.path.join(d, f), "rb").read())) == sorted(_records(open(os.path.join(one, f), "rb").read())), f
+    if name != "wgs_pe_variants":
+        return
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", "-m", "simuscop_amd.run", cfg, "--seed", str(SEED), "--merge", "--backend", "gloo",
+                        "--shard-contigs"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_dir = [l.split("=", 1)[1].strip() for l in open(cfg) if l.startswith("output")][0]
+    for f in _files(one):
+        assert sorted(_records(open(os.path.join(out_dir, f), "rb").read())) == sorted(_records(open(os.path.join(one, f), "rb").read())), f

@@ -24,8 +24,12 @@ def _md5(path):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("name", sorted(cases.CASES))
+SLOW = sorted(cases.SLOW_CASES) if os.environ.get("SIMU_SLOW_TESTS") else []
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES) + SLOW)
 def test_oracle_mt_reproduces_reference(name, oracle_lib, tmp_path):
+    """(The full-coverage C3 / C4 cases take minutes on the sequential mt mode: run them with SIMU_SLOW_TESTS=1.)"""
     assert name in GOLDEN, "run tests/golden/make_golden.py"
     cfg = cases.build_case(name, str(tmp_path))
     g = GOLDEN[name]
@@ -40,6 +44,17 @@ def test_oracle_mt_reproduces_reference(name, oracle_lib, tmp_path):
         assert _md5(fq) == exp["md5"], f"{name}/{os.path.basename(fq)} differs from the reference"
         total += exp["reads"]
     assert oracle_lib.orc_last_read_count() == total
+
+
+def test_golden_pins_the_named_baseline_configs():
+    """BASELINE configs[3] / [4] (C3: 24 contigs in GRCh38 proportions, XTen PE; C4: four populations, tumour
+    variation pattern, abundance row, XTen PE) are pinned on the reference binary at reduced AND at their own
+    coverage (30x / 60x)."""
+    for name in ("c3_grch38_pe_xten_cov3", "c3_grch38_pe_xten_cov30", "c4_tumor_pe_xten_cov6", "c4_tumor_pe_xten_cov60"):
+        assert name in GOLDEN, name
+    assert sum(f["reads"] for f in GOLDEN["c3_grch38_pe_xten_cov30"]["files"].values()) > 4_000_000
+    c4 = GOLDEN["c4_tumor_pe_xten_cov60"]["files"]
+    assert sorted(c4) == ["clone1_0.300+clone2_0.250+clone3_0.350+normal_0.100_1.fq", "clone1_0.300+clone2_0.250+clone3_0.350+normal_0.100_2.fq"]
 
 
 def test_golden_covers_edge_cases():
