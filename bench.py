@@ -55,12 +55,15 @@ def cpu_baseline(workdir, profile="Illumina_HiSeqXTen.profile"):
     """Time the reference's CPU thread-pool path on a bounded sample of the same workload, on ALL host cores.
 
     Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
-    Fallback (binary absent): the oracle restatement (kind "port").  Sample: ONE contig of the same synthetic
-    genome at 30x with one <=1 Mbp segment per worker thread -- the reference's unit of parallelism is the segment,
-    with a barrier per chromosome (Genome.cpp:876-883), so a chromosome shorter than `cores` Mbp leaves cores idle."""
+    Fallback (binary absent): the oracle restatement (kind "port").  Sample: the C2 chromosome itself (64.4 Mbp at
+    30x) on boxes with many cores, a 16 Mbp contig of the same genome on small ones.  The reference's unit of
+    parallelism is the <=1 Mbp segment with a barrier per chromosome (Genome.cpp:876-883): 65 work items for this
+    chromosome, whatever `threads` says (on the 256-core GPU box a 256 Mbp contig -- one segment per core -- ran at
+    0.15 M pairs/s against 0.36 M pairs/s on 16 threads: its load and haplotype passes are serial and its writer
+    is one mutex, lib/seqwriter/SeqWriter.cpp:49-54)."""
     from simuscop_amd import synth
     cores = os.cpu_count() or 1
-    sample_len = min(256_000_000, max(16, cores) * 1_000_000)
+    sample_len = CHR20_LEN if cores >= 32 else 16_000_000
     fa = os.path.join(workdir, "cpu_sample.fa")
     synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
     cfg = os.path.join(workdir, "cpu_config.txt")
