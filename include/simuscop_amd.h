@@ -189,6 +189,27 @@ int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2);
 typedef struct sg_gc_window { uint64_t start; uint32_t chain; uint32_t len; } sg_gc_window;
 int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t* gc_out);
 
+/* GC-bias weight of sampling windows, on the device: Segment::getWeightedLength's per-window loop
+ * (lib/segment/Segment.cpp:550-641) -- GC% of the window (calculateGCPercent, lib/mydefine/MyDefine.cpp:279-303),
+ * GC factor = Normal(means[gc], std) redrawn while negative (Profile::getGCFactor, lib/profile/Profile.cpp:1507-1517),
+ * weight = factor / frag_size for a window of exactly frag_size bases when full_tile_form is set (Segment.cpp:576,586),
+ * else factor * len / frag_size^2 (:615).  The normal variate is addressed (Philox kind GC: window ordinal, attempt,
+ * segment ordinal, ctx24 = population << 16 | chromosome) and read off the quantile table of the model -- n_cells + 1
+ * knots of the standard normal's quantile function, cell = draw >> (32 - lg_cells), linear inside the cell -- in three
+ * rounded fp64 operations, so the weights are bit for bit those of the host evaluation of the same table.
+ * weights_out / gc_out (either may be NULL) receive n values each. */
+typedef struct sg_gc_model {
+  const double* means;      /* [101] */
+  double std;
+  const double* quantiles;  /* [2^lg_cells + 1] */
+  uint32_t lg_cells;
+  uint32_t frag_size;
+  int32_t full_tile_form;
+  uint32_t ctx24;
+} sg_gc_model;
+int sg_window_weights(sg_ctx* ctx, const sg_gc_window* windows, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
+                      const sg_gc_model* model, double* weights_out, int32_t* gc_out);
+
 /* ---- instrumentation ----------------------------------------------------------------------- */
 #define SG_K_PLAN 0
 #define SG_K_NAMEBASE 1

@@ -594,12 +594,37 @@ struct Profile {
     normParas();
     initCDFs(rng);
     countIndelDraws();
-    if (rng.philox) buildIntegerTables();
+    if (rng.philox) { buildIntegerTables(); buildNormalQuantiles(); }
   }
   int maxInsertSize() const { return iSizeAlphabet.empty() ? insertSize : iSizeAlphabet.back(); }
 
-  // Profile::getGCFactor, Profile.cpp:1507-1517.  philox: Box-Muller on draws addressed by
-  // (popu, chr, seg ordinal, window ordinal, attempt).
+  // Philox mode: the standard normal behind the GC factor comes from a fixed quantile table, so that a GPU can
+  // reproduce it bit for bit without log / cos: NQ = 2^14 cells of equal probability, knots Q[k] = Phi^-1(k / NQ)
+  // (Q[0] = Phi^-1(1 / (4 NQ)), Q[NQ - k] = -Q[k]), found by 64 bisection steps on 0.5 * erfc(-z / sqrt 2) in fp64.
+  // A 32-bit draw x picks cell x >> 18 and interpolates linearly inside it at t = (2 (x & 0x3FFFF) + 1) / 2^19:
+  //   z = Q[k] + (Q[k+1] - Q[k]) * t          (three fp64 operations, each rounded: no fused multiply-add)
+  // The result is a normal variate up to the piecewise-linear quantile (total variation ~1e-5, tails end at 4.3 sigma).
+  static const int kNormCells = 1 << 14;
+  vector<double> gcQ;
+  void buildNormalQuantiles() {
+    const int N = kNormCells;
+    gcQ.assign(N + 1, 0.0);
+    auto quantile = [](double p) {
+      double lo = -10.0, hi = 0.0;
+      for (int it = 0; it < 64; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (0.5 * erfc(-mid * 0.7071067811865476) < p) lo = mid; else hi = mid;
+      }
+      return 0.5 * (lo + hi);
+    };
+    for (int k = 0; k < N / 2; k++) {
+      const double q = quantile(k == 0 ? 0.25 / N : (double)k / N);
+      gcQ[k] = q;
+      gcQ[N - k] = -q;
+    }
+  }
+  // Profile::getGCFactor, Profile.cpp:1507-1517.  philox: draws addressed by (popu, chr, seg ordinal, window
+  // ordinal, attempt) through the quantile table above.
   double getGCFactor(int gc, Rng& rng, uint32_t ctx24, uint32_t segOrd, uint32_t winOrd) {
     if (gc < 0 || gc > 100) return 0;
     if (!rng.philox) {
@@ -609,10 +634,11 @@ struct Profile {
     }
     for (uint32_t a = 0;; a++) {
       Philox4 o = philox4x32_10(winOrd, a, segOrd, KIND_GC | (ctx24 << 8), rng.k0, rng.k1);
-      double u1 = ((double)o.v[0] + 1.0) / 4294967296.0;
-      double u2 = (double)o.v[1] / 4294967296.0;
-      double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-      double v = gcMeans[gc] + gcStd * z;
+      const uint32_t k = o.v[0] >> 18, f = o.v[0] & 0x3FFFFu;
+      const double t = (double)(2u * f + 1u) * (1.0 / 524288.0);
+      const double d = gcQ[k + 1] - gcQ[k];
+      const double z = gcQ[k] + d * t;
+      const double v = gcMeans[gc] + gcStd * z;
       if (v >= 0) return v;
     }
   }

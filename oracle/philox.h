@@ -38,7 +38,7 @@ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint3
 // device kinds: ctx24 = (mate << 23) | batch_id
 enum PhiloxKind : uint32_t {
   KIND_HAP = 1,    // c0 = segment ordinal in (popu,chr), c1 = draw index            -> v[0]
-  KIND_GC = 2,     // c0 = window ordinal in segment, c1 = attempt, c2 = seg ordinal -> v[0],v[1]
+  KIND_GC = 2,     // c0 = window ordinal in segment, c1 = attempt, c2 = seg ordinal -> v[0]: cell and position of the quantile table
   KIND_PLAN = 3,   // c0 = window index in batch, c1 = attempt        -> [pos, isz, strand, -]
   KIND_INDEL = 4,  // c0 = pair slot, c1 = j/8, c2 = 0: 16-bit heads of the eight positions' 64-bit indel draws (word p/2);
                    //                            c2 = 1+q: 48-bit tails of positions 2q (words 0,1) and 2q+1 (words 2,3)

@@ -230,16 +230,21 @@ sg_profile_cdf Profile::view() const {
   return v;
 }
 
-double Profile::gc_factor(int gc, uint64_t seed, uint32_t ctx24, uint32_t seg_ord, uint32_t win_ord) const {
-  if (gc < 0 || gc > 100) return 0;
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  for (uint32_t a = 0;; a++) {
-    Philox4 o = philox4x32_10(win_ord, a, seg_ord, KIND_GC | (ctx24 << 8), k0, k1);
-    double u1 = ((double)o.v[0] + 1.0) / 4294967296.0;
-    double u2 = (double)o.v[1] / 4294967296.0;
-    double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    double v = gc_means[gc] + gc_std * z;
-    if (v >= 0) return v;
+void Profile::build_gc_quantiles() {
+  const int N = 1 << 14;
+  gc_quantiles.assign(N + 1, 0.0);
+  auto quantile = [](double p) {
+    double lo = -10.0, hi = 0.0;
+    for (int it = 0; it < 64; it++) {
+      const double mid = 0.5 * (lo + hi);
+      if (0.5 * erfc(-mid * 0.7071067811865476) < p) lo = mid; else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+  };
+  for (int k = 0; k < N / 2; k++) {
+    const double q = quantile(k == 0 ? 0.25 / N : (double)k / N);
+    gc_quantiles[k] = q;
+    gc_quantiles[N - k] = -q;
   }
 }
 

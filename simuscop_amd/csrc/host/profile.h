@@ -27,7 +27,11 @@ struct Profile {
   // view for sg_load_profile (pointers stay valid while *this lives)
   sg_profile_cdf view() const;
   // Profile::getGCFactor (Profile.cpp:1507-1517) with an addressed Philox Box-Muller draw
-  double gc_factor(int gc, uint64_t seed, uint32_t ctx24, uint32_t seg_ord, uint32_t win_ord) const;
+  // The standard normal behind the GC factor (Profile::getGCFactor, Profile.cpp:1507-1517) as a quantile table the
+  // device interpolates (sg_window_weights): 2^14 cells of equal probability, knots Phi^-1(k / 2^14) by bisection on
+  // erfc (DESIGN.md section 4 "GC factor").
+  std::vector<double> gc_quantiles;
+  void build_gc_quantiles();
 
  private:
   int kmer_index(const std::string& s) const;  // Profile::initKmers order (Profile.cpp:70-124)

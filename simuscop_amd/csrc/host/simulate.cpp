@@ -129,50 +129,35 @@ struct Driver {
     st.t_haplotypes += since(t0);
     t0 = Clock::now();
     upload(popu, chr);
+    // GC%, GC factor and weight of every window on the device (sg_window_weights); the draws of the factor are
+    // addressed by (segment ordinal, window ordinal inside the segment)
     gcw.clear();
-    std::vector<uint32_t> widx;
-    for (const Segment& g : plan.segs) {
+    std::vector<uint32_t> widx, seg_ord, win_ord;
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+      const Segment& g = plan.segs[k];
       if (!g.has_seq || (!genome.targets.empty() && g.targets.empty())) continue;  // placeholder windows carry no GC draw
       for (uint32_t w = g.w0; w < g.w1; w++) {
         gcw.push_back(sg_gc_window{g.hap_base[plan.w_hap[w]] + plan.w_spos[w], plan.w_hap[w], plan.w_len[w]});
         widx.push_back(w);
+        seg_ord.push_back((uint32_t)k);
+        win_ord.push_back(w - g.w0);
       }
     }
-    gcv.assign(gcw.size(), 0);
-    eng.check(sg_gc_percent(eng.ctx, gcw.data(), gcw.size(), gcv.data()), "sg_gc_percent");
-    const uint32_t ctx24 = genome.host_ctx(popu, chr);
-    const unsigned frag = Genome::kFragSize;
-    // GC factor per window: an addressed draw (segment, window), so segments are independent work
-    std::vector<size_t> q0(plan.segs.size() + 1, 0);
-    for (size_t k = 0; k < plan.segs.size(); k++) {
-      const Segment& g = plan.segs[k];
-      const bool live = g.has_seq && !(!genome.targets.empty() && g.targets.empty());
-      q0[k + 1] = q0[k] + (live ? g.w1 - g.w0 : 0);
-    }
-    auto weigh_segment = [&](size_t k) {
-      const Segment& g = plan.segs[k];
-      if (q0[k + 1] == q0[k]) return;
-      size_t q = q0[k];
-      for (uint32_t w = g.w0; w < g.w1; w++, q++) {
-        const double f = prof.gc_factor(gcv[q], seed, ctx24, (uint32_t)k, w - g.w0);
-        // full 1 kbp tiles: factor/fragSize; tails and targets: factor*len/(fragSize*fragSize)
-        // (Segment.cpp:576,586,615 -- the two forms round differently, keep both)
-        if (genome.targets.empty() && plan.w_len[w] == frag) plan.w_weight[w] = f / frag;
-        else plan.w_weight[w] = f * (unsigned long)plan.w_len[w] / (frag * frag);
-      }
-    };
-    const size_t nthreads = std::min<size_t>((size_t)std::max<long long>(1, cfg.num["threads"]), plan.segs.size() / 4 + 1);
-    if (nthreads <= 1) {
-      for (size_t k = 0; k < plan.segs.size(); k++) weigh_segment(k);
-    } else {
-      std::atomic<size_t> next(0);
-      std::vector<std::thread> pool;
-      for (size_t t = 0; t < nthreads; t++)
-        pool.emplace_back([&]() {
-          for (size_t k; (k = next.fetch_add(1)) < plan.segs.size();) weigh_segment(k);
-        });
-      for (std::thread& th : pool) th.join();
-    }
+    if (prof.gc_quantiles.empty()) prof.build_gc_quantiles();
+    sg_gc_model model;
+    model.means = prof.gc_means;
+    model.std = prof.gc_std;
+    model.quantiles = prof.gc_quantiles.data();
+    model.lg_cells = 14;
+    model.frag_size = Genome::kFragSize;
+    // full 1 kbp tiles: factor/fragSize; tails and targets: factor*len/(fragSize*fragSize)
+    // (Segment.cpp:576,586,615 -- the two forms round differently, keep both)
+    model.full_tile_form = genome.targets.empty() ? 1 : 0;
+    model.ctx24 = genome.host_ctx(popu, chr);
+    std::vector<double> wts(gcw.size());
+    eng.check(sg_window_weights(eng.ctx, gcw.data(), seg_ord.data(), win_ord.data(), gcw.size(), &model, wts.data(), nullptr),
+              "sg_window_weights");
+    for (size_t q = 0; q < widx.size(); q++) plan.w_weight[widx[q]] = wts[q];
     plan.weighed = true;
     st.t_plan += since(t0);
   }

@@ -29,6 +29,9 @@ bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 int emit_variant(const DevProfile& P);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
+void launch_gc_weight(const int32_t* gc, const sg_gc_window* wins, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
+                      const double* means, double std, const double* Q, uint32_t lg_cells, uint32_t frag, int32_t full_tile_form,
+                      uint32_t ctx24, uint64_t seed, double* out, hipStream_t s);
 // sg_haplotypes.hip
 struct DevContig { uint64_t raw_off, code_off, length; uint32_t line_bases, line_width; uint64_t first_block; };
 struct DevPiece { uint64_t dst, src; uint32_t len, pad; };
@@ -99,7 +102,7 @@ struct sg_ctx {
   sg::DevProfile P{};
   sg::DevBatch B{};
   DevBuf tab, chains, chains2, chain_meta, windows, segmeta, prefix, pairs, win_actual, win_namebase, rlen, events, reclen,
-      recoff, meta, totals, bsum, out1, out2, gcw, gco, slowq, ref_raw, ref_codes, ref_meta, hap_work, gz1, gz2, gz_work;
+      recoff, meta, totals, bsum, out1, out2, gcw, gco, gcm, slowq, ref_raw, ref_codes, ref_meta, hap_work, gz1, gz2, gz_work;
   uint64_t gz_bytes[2] = {0, 0};
   bool gz_valid = false;
   std::vector<sg_outputs*> spare;  // released output sets, reused by the next pass
@@ -203,7 +206,7 @@ void sg_destroy(sg_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chains2, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
-                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->slowq,
+                    &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->gcm, &ctx->slowq,
                     &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work, &ctx->gz1, &ctx->gz2, &ctx->gz_work})
     b->release();
   for (sg_outputs* o : ctx->spare) {
@@ -1119,6 +1122,45 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
   SG_HIP(hipGetLastError());
   SG_HIP(hipMemcpyAsync(gc_out, ctx->gco.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   SG_HIP(hipStreamSynchronize(ctx->stream));
+  return SG_OK;
+}
+
+int sg_window_weights(sg_ctx* ctx, const sg_gc_window* windows, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
+                      const sg_gc_model* model, double* weights_out, int32_t* gc_out) {
+  if (!ctx || !model || !model->means || !model->quantiles || (n && (!windows || !seg_ord || !win_ord))) return SG_ERR_INVALID;
+  if (model->lg_cells < 1 || model->lg_cells > 20 || model->frag_size == 0) return ctx->fail(SG_ERR_INVALID, "sg_window_weights: bad model");
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_window_weights: call sg_upload_haplotypes first");
+  if (!n) return SG_OK;
+  SG_HIP(hipSetDevice(ctx->device));
+  {
+    const size_t nch = (size_t)(ctx->B.chain_len - ctx->B.chain_off);
+    std::vector<uint64_t> meta(2 * nch);
+    if (nch) SG_HIP(hipMemcpy(meta.data(), ctx->chain_meta.p, meta.size() * 8, hipMemcpyDeviceToHost));
+    for (uint64_t w = 0; w < n; w++) {
+      if (windows[w].chain >= nch) return ctx->fail(SG_ERR_INVALID, "sg_window_weights: chain out of range");
+      if (windows[w].start + windows[w].len > meta[nch + windows[w].chain]) return ctx->fail(SG_ERR_INVALID, "sg_window_weights: window runs past its chain");
+    }
+  }
+  // device work buffer: windows | seg_ord | win_ord | gc | weights | means[101] + quantile knots
+  const size_t cells = (size_t)1 << model->lg_cells;
+  const size_t o_seg = n * sizeof(sg_gc_window), o_win = o_seg + n * 4, o_gc = o_win + n * 4, o_wt = (o_gc + n * 4 + 7) & ~(size_t)7;
+  SG_ENSURE(ctx->gcw, o_wt + n * 8);
+  SG_ENSURE(ctx->gcm, (101 + cells + 1) * 8);
+  uint8_t* wk = ctx->gcw.as<uint8_t>();
+  hipStream_t s = ctx->stream;
+  SG_HIP(hipMemcpyAsync(wk, windows, n * sizeof(sg_gc_window), hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(wk + o_seg, seg_ord, n * 4, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(wk + o_win, win_ord, n * 4, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(ctx->gcm.p, model->means, 101 * 8, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(ctx->gcm.as<double>() + 101, model->quantiles, (cells + 1) * 8, hipMemcpyHostToDevice, s));
+  sg::launch_gc(ctx->B.chains, ctx->B.chain_off, (const sg_gc_window*)wk, n, (int32_t*)(wk + o_gc), s);
+  sg::launch_gc_weight((const int32_t*)(wk + o_gc), (const sg_gc_window*)wk, (const uint32_t*)(wk + o_seg), (const uint32_t*)(wk + o_win), n,
+                       ctx->gcm.as<double>(), model->std, ctx->gcm.as<double>() + 101, model->lg_cells, model->frag_size,
+                       model->full_tile_form, model->ctx24, ctx->seed, (double*)(wk + o_wt), s);
+  SG_HIP(hipGetLastError());
+  if (weights_out) SG_HIP(hipMemcpyAsync(weights_out, wk + o_wt, n * 8, hipMemcpyDeviceToHost, s));
+  if (gc_out) SG_HIP(hipMemcpyAsync(gc_out, wk + o_gc, n * 4, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
   return SG_OK;
 }
 

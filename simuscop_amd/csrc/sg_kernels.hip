@@ -1449,6 +1449,39 @@ __global__ __launch_bounds__(256) void gc_kernel(const uint8_t* __restrict__ cha
   if (lane == 0) out[w] = win.len == 0 ? 0 : (nn > 0 ? -1 : (int32_t)(100u * gc / win.len));
 }
 
+// GC factor and weight of a window (Profile::getGCFactor, Profile.cpp:1507-1517; Segment.cpp:576,586,615): one lane
+// per window, the normal variate interpolated from the quantile table in three rounded fp64 operations (no fused
+// multiply-add: the host / oracle evaluation of the same table must give the same bits)
+__global__ __launch_bounds__(256) void gc_weight_kernel(const int32_t* __restrict__ gc, const sg_gc_window* __restrict__ wins,
+                                                        const uint32_t* __restrict__ seg_ord, const uint32_t* __restrict__ win_ord,
+                                                        uint64_t n, const double* __restrict__ means, double std,
+                                                        const double* __restrict__ Q, uint32_t lg_cells, uint32_t frag,
+                                                        int32_t full_tile_form, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                        double* __restrict__ out) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const int32_t g = gc[w];
+  double f = 0.0;
+  if (g >= 0 && g <= 100) {
+    const double mean = means[g];
+    const uint32_t tail_bits = 32u - lg_cells;
+    const double scale = 1.0 / (double)(1ull << (tail_bits + 1u));
+    for (uint32_t a = 0;; a++) {
+      uint32_t x[4];
+      philox4x32_10(win_ord[w], a, seg_ord[w], c3, k0, k1, x);
+      const uint32_t k = x[0] >> tail_bits, fr = x[0] & ((1u << tail_bits) - 1u);
+      const double t = __dmul_rn((double)(2u * fr + 1u), scale);
+      const double d = __dsub_rn(Q[k + 1], Q[k]);
+      const double z = __dadd_rn(Q[k], __dmul_rn(d, t));
+      f = __dadd_rn(mean, __dmul_rn(std, z));
+      if (f >= 0.0) break;
+    }
+  }
+  const uint32_t len = wins[w].len;
+  out[w] = (full_tile_form && len == frag) ? __ddiv_rn(f, (double)frag)
+                                           : __ddiv_rn(__dmul_rn(f, (double)len), (double)((uint64_t)frag * frag));
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (called from sg_api.cpp through plain C++ declarations)
 // ------------------------------------------------------------------------------------------------
@@ -1587,6 +1620,13 @@ void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s) {  // bytes is a m
   const size_t n16 = bytes / 16;
   uint32_t grid = (uint32_t)std::min<size_t>((n16 + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(256), 0, s, (uint4*)buf, n16);
+}
+void launch_gc_weight(const int32_t* gc, const sg_gc_window* wins, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
+                      const double* means, double std, const double* Q, uint32_t lg_cells, uint32_t frag, int32_t full_tile_form,
+                      uint32_t ctx24, uint64_t seed, double* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(gc_weight_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gc, wins, seg_ord, win_ord, n, means, std, Q,
+                     lg_cells, frag, full_tile_form, KIND_GC | (ctx24 << 8), (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s) {
   if (!n) return;
