@@ -200,20 +200,20 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   // calls, almost always a real event); then only the flagged positions are walked.
   const uint64_t cI = (uint64_t)P.Tins + 1ull, A64 = cI << 32, B64 = A64 + ((1ull << 32) - cI) * (uint64_t)P.Cdel;
   const uint32_t hA = (uint32_t)(A64 >> 48), hB = (uint32_t)(B64 >> 48);
-  for (int c = 0; 8 * c < L; c++) {
-    if (8 * c + 7 < j) continue;  // all eight positions were consumed by a deletion
-    uint32_t x[4];
-    philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
+  // One chunk of eight positions: the flagged ones are walked in order (j = first position not covered by a deletion
+  // so far).  Rare work: run for the few lanes that have a candidate, after the scan below.
+  auto walk_chunk = [&](int c, const uint32_t (&x)[4]) {
     uint32_t cand = 0;
 #pragma unroll
     for (int p = 0; p < 8; p++) cand |= (uint32_t)(((x[p >> 1] >> (16 * (p & 1))) & 0xFFFFu) <= hB) << p;
-    if (__ballot(cand != 0u) == 0ull) continue;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      if (__ballot((cand >> p) & 1u) == 0ull) continue;
+#pragma unroll 1
+    while (cand) {
+      const int p = __builtin_ctz(cand);
+      cand &= cand - 1u;
       const int jj = 8 * c + p;
-      if (!((cand >> p) & 1u) || jj >= L || jj < j) continue;  // j: first position not covered by a deletion so far
-      const uint32_t head = (x[p >> 1] >> (16 * (p & 1))) & 0xFFFFu;
+      if (jj >= L || jj < j) continue;
+      const uint32_t w = p < 2 ? x[0] : p < 4 ? x[1] : p < 6 ? x[2] : x[3];
+      const uint32_t head = (w >> (16 * (p & 1))) & 0xFFFFu;
       bool is_ins = head < hA, is_del = head > hA && head < hB;
       if (head == hA || head == hB) {
         uint32_t y[4];
@@ -242,6 +242,46 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
           j = jj + (int)k;
         }
       }
+    }
+  };
+  // smallest of a call's eight 16-bit heads (packed 16-bit minima)
+  auto min_head = [](const uint32_t (&x)[4]) -> uint32_t {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 a = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x[0]), __builtin_bit_cast(u16x2, x[1]));
+    const u16x2 b2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x[2]), __builtin_bit_cast(u16x2, x[3]));
+    const u16x2 c2 = __builtin_elementwise_min(a, b2);
+    return min((uint32_t)c2.x, (uint32_t)c2.y);
+  };
+  const int nch = (L + 7) / 8;
+  if (nch <= 64) {
+    // Scan: one Philox call per chunk, nothing else -- a chunk with a head at or below B's (1 % of them) is a bit in
+    // the lane's mask.  Then the lanes with candidates walk theirs, in order, a chunk per round: the rounds (two or
+    // three per wave) serve all candidate lanes at once, where handling a candidate on the spot stalled the whole
+    // wave in a quarter of the calls.
+    unsigned long long cmask = 0;
+    for (int c = 0; c < nch; c++) {
+      uint32_t x[4];
+      philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
+      cmask |= (unsigned long long)(min_head(x) <= hB) << c;
+    }
+    while (__ballot(cmask != 0ull) != 0ull) {
+      if (cmask != 0ull) {
+        const int c = __builtin_ctzll(cmask);
+        cmask &= cmask - 1ull;
+        if (8 * c + 7 >= j) {  // not wholly consumed by a deletion
+          uint32_t x[4];
+          philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
+          walk_chunk(c, x);
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < nch; c++) {  // reads of more than 512 bases: chunk by chunk
+      if (8 * c + 7 < j) continue;
+      uint32_t x[4];
+      philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
+      if (__ballot(min_head(x) <= hB) == 0ull) continue;
+      if (min_head(x) <= hB) walk_chunk(c, x);
     }
   }
   if (L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
