@@ -210,6 +210,42 @@ typedef struct sg_gc_model {
 int sg_window_weights(sg_ctx* ctx, const sg_gc_window* windows, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
                       const sg_gc_model* model, double* weights_out, int32_t* gc_out);
 
+/* ---- sampling plan made on the device (whole-genome runs without targets) ------------------- */
+/* The reference tiles every haplotype string of a segment into frag_size windows (Segment::getWeightedLength,
+ * Segment.cpp:566-590), weighs them (sg_window_weights), sums the weights per segment, chromosome and genome
+ * (Genome::setReadCounts, Genome.cpp:783-825) and hands every window fragWeights[i] * readCount / totalWL reads,
+ * the remainder going to the segment's first window (Segment::setReadCount, Segment.cpp:462-476).  Here the host
+ * only keeps per-SEGMENT data; the windows exist on the device alone:
+ *   sg_windows_build   tiles the generators (one per haplotype string of a segment, in the reference's window order),
+ *                      computes GC%, GC factor and weight of every window and the weight sum of every segment (summed
+ *                      in window order, like the reference's loop); the weights stay in the context under `store_id`;
+ *   sg_plan_windows    for the segments that got reads: per-window read counts, the remainder rule, planned pairs and
+ *                      their prefix sum -- the sg_window table of the batch, on the device; reports the planned
+ *                      fragments of every active segment (the host cuts pieces / shards by them);
+ *   sg_plan_range      makes a run [a0, a1) of those active segments the current batch (what sg_plan does for a
+ *                      host-made table); first_window / first_slot keep the draws' batch-wide addresses.        */
+typedef struct sg_window_gen {
+  uint64_t hap_base;      /* offset of the haplotype string inside chain `chain`                               */
+  uint64_t hap_len;       /* its length; windows = ceil(hap_len / frag_size), the last one shorter               */
+  uint32_t chain;
+  uint32_t seg;           /* sg_windows_build: segment ordinal in the chromosome; sg_plan_windows: index in `active` */
+  uint64_t first_window;  /* sg_plan_windows: index of the generator's first window in the numbering of sg_windows_build */
+} sg_window_gen;
+int sg_windows_build(sg_ctx* ctx, uint32_t store_id, const sg_window_gen* gens, uint64_t n_gens, uint32_t n_segs,
+                     const sg_gc_model* model, double* seg_weight_out, uint64_t* n_windows_out);
+typedef struct sg_active_seg {
+  int64_t reads;          /* Segment::readCount                                                                */
+  double weight;          /* the segment's weight sum (seg_weight_out of sg_windows_build)                     */
+  uint32_t seg_size;      /* seqSize / CN (Segment.cpp:713-714)                                                */
+  uint32_t pad;
+} sg_active_seg;
+int sg_plan_windows(sg_ctx* ctx, uint32_t store_id, const sg_window_gen* gens, uint64_t n_gens, const sg_active_seg* active,
+                    uint32_t n_active, uint32_t frag_size, uint32_t batch_id, int32_t paired, const char* name_prefix,
+                    uint64_t* slots_out /* [n_active] */, uint64_t* n_windows_out);
+int sg_plan_range(sg_ctx* ctx, uint32_t a0, uint32_t a1);
+void sg_windows_drop(sg_ctx* ctx);  /* frees every window-weight store of the context */
+
+
 /* ---- instrumentation ----------------------------------------------------------------------- */
 #define SG_K_PLAN 0
 #define SG_K_NAMEBASE 1

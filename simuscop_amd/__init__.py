@@ -26,7 +26,7 @@ ENGINE_SYMBOLS = [
     "sg_bgzf_eof", "sg_deflate_plan", "sg_detach_outputs", "sg_outputs_sizes", "sg_outputs_fetch",
     "sg_outputs_last_error", "sg_release_outputs", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
-    "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights",
+    "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
     "sg_host_free",
 ]
 

@@ -61,6 +61,12 @@ struct ChromPlan {  // one (population, chromosome)
   bool chains_built = false, windows_built = false, weighed = false;
   std::vector<uint32_t> w_spos, w_len, w_hap;  // Segment::fragStartPos / (End-Start+1) / hapIndxs
   std::vector<double> w_weight;                // Segment::fragWeights
+  // whole-genome runs (no targets): the windows exist on the device only (sg_windows_build / sg_plan_windows); the
+  // host keeps one weight sum and one first-window index per segment
+  bool dev_windows = false;
+  std::vector<double> seg_w;
+  std::vector<uint64_t> seg_win0;
+  uint32_t store_id = 0;
 };
 
 struct Genome {

@@ -125,10 +125,46 @@ struct Driver {
     if (plan.weighed) return;
     auto t0 = Clock::now();
     genome.build_chains(popu, chr, seed);   // no-ops when prebuild() already did them
-    genome.build_windows(popu, chr);
+    if (!dev_plan()) genome.build_windows(popu, chr);
     st.t_haplotypes += since(t0);
     t0 = Clock::now();
     upload(popu, chr);
+    if (dev_plan()) {
+      // Windows, GC%, GC factors, weights and the per-segment weight sums on the device: the host never sees a window
+      if (prof.gc_quantiles.empty()) prof.build_gc_quantiles();
+      std::vector<sg_window_gen> gens;
+      plan.seg_win0.assign(plan.segs.size(), 0);
+      uint64_t nwin = 0;
+      for (size_t k = 0; k < plan.segs.size(); k++) {
+        Segment& g = plan.segs[k];
+        plan.seg_win0[k] = nwin;
+        g.w0 = (uint32_t)nwin;
+        if (g.has_seq)
+          for (size_t h = 0; h < g.hap_len.size(); h++) {  // 1 kbp tiles + a shorter tail per haplotype string (Segment.cpp:563-592)
+            if (!g.hap_len[h]) continue;
+            gens.push_back(sg_window_gen{g.hap_base[h], g.hap_len[h], (uint32_t)h, (uint32_t)k, 0});
+            nwin += (g.hap_len[h] + Genome::kFragSize - 1) / Genome::kFragSize;
+          }
+        g.w1 = (uint32_t)nwin;
+      }
+      sg_gc_model model;
+      model.means = prof.gc_means;
+      model.std = prof.gc_std;
+      model.quantiles = prof.gc_quantiles.data();
+      model.lg_cells = 14;
+      model.frag_size = Genome::kFragSize;
+      model.full_tile_form = 1;
+      model.ctx24 = genome.host_ctx(popu, chr);
+      plan.store_id = model.ctx24;
+      plan.seg_w.assign(plan.segs.size(), 0.0);
+      uint64_t n_out = 0;
+      eng.check(sg_windows_build(eng.ctx, plan.store_id, gens.data(), gens.size(), (uint32_t)plan.segs.size(), &model, plan.seg_w.data(), &n_out),
+                "sg_windows_build");
+      plan.dev_windows = true;
+      plan.weighed = true;
+      st.t_plan += since(t0);
+      return;
+    }
     // GC%, GC factor and weight of every window on the device (sg_window_weights); the draws of the factor are
     // addressed by (segment ordinal, window ordinal inside the segment)
     gcw.clear();
@@ -162,7 +198,13 @@ struct Driver {
     st.t_plan += since(t0);
   }
 
+  // windows made on the device (whole-genome runs; SIMU_HOST_PLAN=1 keeps the host planner for comparison runs)
+  bool dev_plan() const {
+    static const bool host_plan = getenv("SIMU_HOST_PLAN") != nullptr;
+    return genome.targets.empty() && !host_plan;
+  }
   static double seg_weight(const ChromPlan& plan, const Segment& g) {
+    if (plan.dev_windows) return plan.seg_w[(size_t)(&g - plan.segs.data())];
     double s = 0;
     for (uint32_t w = g.w0; w < g.w1; w++) s += plan.w_weight[w];
     return s;
@@ -188,7 +230,7 @@ struct Driver {
           if (i >= todo.size()) return;
           try {
             genome.build_chains(popu, todo[i], seed);
-            genome.build_windows(popu, todo[i]);
+            if (!dev_plan()) genome.build_windows(popu, todo[i]);
           } catch (const std::exception& e) {
             std::lock_guard<std::mutex> lk(err_mu);
             if (err.empty()) err = e.what();
@@ -263,6 +305,7 @@ struct Driver {
     std::vector<Active> act;
     uint64_t slots = 0;
     size_t a0 = 0, a1 = 0;  // this process's run of active segments (multi-GPU shard)
+    bool dev = false;       // the window table lives on the device (sg_plan_windows)
   } cur;
 
   // false: nothing to sample in the batch (for this process)
@@ -280,6 +323,43 @@ struct Driver {
     std::vector<Active>& act = cur.act;
     wins.clear(); seg_size.clear(); seg_first.clear();
     uint64_t slot = 0;
+    if (plan.dev_windows) {
+      // per-window read counts, the remainder rule, planned pairs and their prefix sums on the device (sg_plan_windows);
+      // the host keeps what it needs to cut the batch into shards and pieces: the planned fragments per segment
+      upload(popu, chr);
+      std::vector<sg_window_gen> gens;
+      std::vector<sg_active_seg> active;
+      for (size_t k = 0; k < plan.segs.size(); k++) {
+        const Segment& g = plan.segs[k];
+        if (!g.has_seq || g.read_count == 0) continue;
+        uint64_t w = plan.seg_win0[k];
+        bool any = false;
+        for (size_t h = 0; h < g.hap_len.size(); h++) {
+          if (!g.hap_len[h]) continue;
+          gens.push_back(sg_window_gen{g.hap_base[h], g.hap_len[h], (uint32_t)h, (uint32_t)active.size(), w});
+          w += (g.hap_len[h] + Genome::kFragSize - 1) / Genome::kFragSize;
+          any = true;
+        }
+        if (!any) throw Error("ERROR: sampling window on an absent haplotype (chromosome " + chr + ")");
+        active.push_back(sg_active_seg{(int64_t)g.read_count, plan.seg_w[k], g.seq_size() / (unsigned)g.cn, 0});
+        seg_size.push_back(g.seq_size() / (unsigned)g.cn);
+        act.push_back(Active{k, 0, 0});
+      }
+      std::vector<uint64_t> slots(active.size(), 0);
+      uint64_t nwin = 0;
+      if (!active.empty())
+        eng.check(sg_plan_windows(eng.ctx, plan.store_id, gens.data(), gens.size(), active.data(), (uint32_t)active.size(), Genome::kFragSize,
+                                  cur.bid, paired ? 1 : 0, cur.prefix.c_str(), slots.data(), &nwin),
+                  "sg_plan_windows");
+      for (size_t i = 0; i < act.size(); i++) { act[i].slots = slots[i]; slot += slots[i]; }
+      cur.dev = true;
+      cur.slots = slot;
+      st.windows += nwin;
+      st.segments += act.size();
+      st.t_plan += since(t0);
+      if (act.empty() || nwin == 0) return false;
+      return shard_range(slot);
+    }
     for (size_t k = 0; k < plan.segs.size(); k++) {
       const Segment& g = plan.segs[k];
       if (!g.has_seq || g.read_count == 0) continue;
@@ -311,8 +391,12 @@ struct Driver {
     st.segments += act.size();
     st.t_plan += since(t0);
     if (wins.empty()) return false;
+    return shard_range(slot);
+  }
 
-    // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
+  // shard by runs of segments (multi-GPU): contiguous, balanced by planned fragments
+  bool shard_range(uint64_t slot) {
+    const std::vector<Active>& act = cur.act;
     cur.a0 = 0; cur.a1 = act.size();
     if (opt.shard_world > 1 && !opt.shard_contigs) {
       const uint64_t per = (slot + opt.shard_world - 1) / opt.shard_world;
@@ -331,6 +415,15 @@ struct Driver {
 
   // chains on the device, sg_plan for the active segments [a0, a1) of the current batch
   void plan_range(size_t a0, size_t a1) {
+    if (cur.dev) {
+      auto t0d = Clock::now();
+      upload(cur.popu, cur.chr);
+      auto t_pl = Clock::now();
+      eng.check(sg_plan_range(eng.ctx, (uint32_t)a0, (uint32_t)a1), "sg_plan_range");
+      st.t_plan_api += since(t_pl);
+      st.t_sample += since(t0d);
+      return;
+    }
     const std::vector<Active>& act = cur.act;
     const uint32_t w_lo = act[a0].w_first;
     const uint32_t w_hi = a1 < act.size() ? act[a1].w_first : (uint32_t)wins.size();

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,15 @@ bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 int emit_variant(const DevProfile& P);
 void launch_encode(uint8_t* buf, size_t bytes, hipStream_t s);
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s);
+void launch_tile(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_gens, uint64_t n, uint32_t frag, const uint64_t* seg_first,
+                 sg_gc_window* out, uint32_t* seg_ord, uint32_t* win_ord, hipStream_t s);
+void launch_seg_sum(const double* wt, const uint64_t* seg_first, uint32_t n_segs, double* out, hipStream_t s);
+void launch_window_reads(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_gens, uint64_t n, uint32_t frag, const double* wt,
+                         const sg_active_seg* act, const uint32_t* seg_first, uint32_t n_act, sg_window* rows, unsigned long long* seg_sum,
+                         int32_t paired, uint32_t* planned, hipStream_t s);
+void launch_slot_base(sg_window* rows, uint64_t n, const uint64_t* off, const uint32_t* seg_first, uint32_t n_act, const uint64_t* total,
+                      uint64_t* seg_slots, hipStream_t s);
+void launch_slice(const sg_window* all, uint64_t w_lo, uint64_t n, uint32_t a0, uint32_t slot_lo, sg_window* out, hipStream_t s);
 void launch_gc_weight(const int32_t* gc, const sg_gc_window* wins, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,
                       const double* means, double std, const double* Q, uint32_t lg_cells, uint32_t frag, int32_t full_tile_form,
                       uint32_t ctx24, uint64_t seed, double* out, hipStream_t s);
@@ -106,6 +116,19 @@ struct sg_ctx {
   uint64_t gz_bytes[2] = {0, 0};
   bool gz_valid = false;
   std::vector<sg_outputs*> spare;  // released output sets, reused by the next pass
+  // device-made sampling plan: window weights per store id (sg_windows_build), the batch table of sg_plan_windows
+  std::map<uint32_t, DevBuf> wstore;
+  std::map<uint32_t, uint64_t> wstore_n;
+  DevBuf wplan, wwork;
+  struct PlanInfo {
+    bool valid = false;
+    uint64_t n_windows = 0;
+    uint32_t n_active = 0, batch_id = 0;
+    int32_t paired = 0;
+    std::string prefix;
+    std::vector<uint32_t> seg_first, seg_size;  // per active segment (seg_first has n_active + 1 entries)
+    std::vector<uint64_t> slot_first;           // planned fragments before each active segment; [n_active] = total
+  } winfo;
   uint64_t ref_raw_bytes = 0;
   std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
@@ -136,6 +159,57 @@ struct sg_ctx {
     int _e = (buf).ensure(bytes);                                                              \
     if (_e) return ctx->hipfail((hipError_t)_e, "hipMalloc(" #buf ")");                        \
   } while (0)
+
+// Work buffers and DevBatch fields of a planned batch whose windows / segment arrays are already in ctx->windows /
+// ctx->segmeta (put there by sg_plan from host arrays, or by sg_plan_range from the device-made table).
+static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slots, uint32_t batch_id, uint32_t first_window,
+                       uint32_t first_slot, int32_t paired, const char* name_prefix) {
+  const size_t plen = name_prefix ? strlen(name_prefix) : 0;
+  const uint32_t nm = paired ? 2 : 1;
+  SG_ENSURE(ctx->prefix, plen + 16);
+  SG_ENSURE(ctx->pairs, ((size_t)n_slots + 1) * sizeof(sg::PairRec));
+  SG_ENSURE(ctx->win_actual, (nw + 1) * 4);
+  SG_ENSURE(ctx->win_namebase, (nw + 1) * 4);
+  SG_ENSURE(ctx->rlen, ((size_t)nm * n_slots + 1) * 4);
+  SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
+  SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
+  SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
+  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
+  SG_ENSURE(ctx->totals, 8 * 8);
+  SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
+  SG_HIP(hipMemcpyAsync(ctx->prefix.p, name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+
+  sg::DevBatch& B = ctx->B;
+  B.windows = ctx->windows.as<sg_window>();
+  B.n_windows = nw;
+  B.seg_size = ctx->segmeta.as<uint32_t>();
+  B.seg_first_window = ctx->segmeta.as<uint32_t>() + n_segs;
+  B.n_segs = n_segs;
+  B.n_slots = n_slots;
+  B.batch_id = batch_id;
+  B.win_offset = first_window;
+  B.slot_offset = first_slot;
+  B.paired = paired ? 1 : 0;
+  B.prefix = ctx->prefix.as<uint8_t>();
+  B.prefix_len = (uint32_t)plen;
+  for (int i = 0; i < 4; i++) B.prefix_w[i] = 0;
+  for (size_t i = 0; i < plen && i < 16; i++) B.prefix_w[i / 4] |= (uint32_t)(uint8_t)name_prefix[i] << (8 * (i % 4));
+  B.pairs = ctx->pairs.as<sg::PairRec>();
+  B.win_actual = ctx->win_actual.as<uint32_t>();
+  B.win_namebase = ctx->win_namebase.as<uint32_t>();
+  B.rlen = ctx->rlen.as<uint32_t>();
+  B.events = ctx->events.as<uint32_t>();
+  B.reclen = ctx->reclen.as<uint32_t>();
+  B.recoff = ctx->recoff.as<uint64_t>();
+  B.meta = ctx->meta.as<uint4>();
+  B.totals = ctx->totals.as<uint64_t>();
+  B.slowq_count = (uint32_t*)(B.totals + 4);
+  ctx->have_plan = true;
+  ctx->sampled = false;
+  ctx->results_valid = false;
+  return SG_OK;
+}
 
 // 2-bit copies of the chains buffer (`total` bytes, a multiple of 1024) for the straight-line emit kernel
 static int pack_chains(sg_ctx* ctx, size_t total) {
@@ -209,6 +283,9 @@ void sg_destroy(sg_ctx* ctx) {
                     &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->gcm, &ctx->slowq,
                     &ctx->ref_raw, &ctx->ref_codes, &ctx->ref_meta, &ctx->hap_work, &ctx->gz1, &ctx->gz2, &ctx->gz_work})
     b->release();
+  for (auto& kv : ctx->wstore) kv.second.release();
+  ctx->wplan.release();
+  ctx->wwork.release();
   for (sg_outputs* o : ctx->spare) {
     for (int m = 0; m < 2; m++) { o->text[m].release(); o->gz[m].release(); }
     if (o->stream) (void)hipStreamDestroy(o->stream);
@@ -888,61 +965,15 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
       if (x.hap_base + x.spos + x.len > meta[nch + x.chain]) return ctx->fail(SG_ERR_INVALID, "sg_plan: window runs past its chain");
     }
   }
-  const uint32_t n_slots = (uint32_t)slots;
-  const uint32_t nm = b->paired ? 2 : 1;
-
   SG_ENSURE(ctx->windows, (nw + 1) * sizeof(sg_window));
   SG_ENSURE(ctx->segmeta, ((size_t)b->n_segs * 2 + 2) * 4);
-  SG_ENSURE(ctx->prefix, plen + 16);
-  SG_ENSURE(ctx->pairs, ((size_t)n_slots + 1) * sizeof(sg::PairRec));
-  SG_ENSURE(ctx->win_actual, (nw + 1) * 4);
-  SG_ENSURE(ctx->win_namebase, (nw + 1) * 4);
-  SG_ENSURE(ctx->rlen, ((size_t)nm * n_slots + 1) * 4);
-  SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
-  SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
-  SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
-  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
-  SG_ENSURE(ctx->totals, 8 * 8);
-  SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
-
   if (nw) SG_HIP(hipMemcpyAsync(ctx->windows.p, b->windows, nw * sizeof(sg_window), hipMemcpyHostToDevice, ctx->stream));
   if (b->n_segs) {
     SG_HIP(hipMemcpyAsync(ctx->segmeta.p, b->seg_size, (size_t)b->n_segs * 4, hipMemcpyHostToDevice, ctx->stream));
     SG_HIP(hipMemcpyAsync(ctx->segmeta.as<uint32_t>() + b->n_segs, b->seg_first_window, ((size_t)b->n_segs + 1) * 4,
                           hipMemcpyHostToDevice, ctx->stream));
   }
-  SG_HIP(hipMemcpyAsync(ctx->prefix.p, b->name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));
-  SG_HIP(hipStreamSynchronize(ctx->stream));
-
-  sg::DevBatch& B = ctx->B;
-  B.windows = ctx->windows.as<sg_window>();
-  B.n_windows = nw;
-  B.seg_size = ctx->segmeta.as<uint32_t>();
-  B.seg_first_window = ctx->segmeta.as<uint32_t>() + b->n_segs;
-  B.n_segs = b->n_segs;
-  B.n_slots = n_slots;
-  B.batch_id = b->batch_id;
-  B.win_offset = b->first_window;
-  B.slot_offset = b->first_slot;
-  B.paired = b->paired ? 1 : 0;
-  B.prefix = ctx->prefix.as<uint8_t>();
-  B.prefix_len = (uint32_t)plen;
-  for (int i = 0; i < 4; i++) B.prefix_w[i] = 0;
-  for (size_t i = 0; i < plen && i < 16; i++) B.prefix_w[i / 4] |= (uint32_t)(uint8_t)b->name_prefix[i] << (8 * (i % 4));
-  B.pairs = ctx->pairs.as<sg::PairRec>();
-  B.win_actual = ctx->win_actual.as<uint32_t>();
-  B.win_namebase = ctx->win_namebase.as<uint32_t>();
-  B.rlen = ctx->rlen.as<uint32_t>();
-  B.events = ctx->events.as<uint32_t>();
-  B.reclen = ctx->reclen.as<uint32_t>();
-  B.recoff = ctx->recoff.as<uint64_t>();
-  B.meta = ctx->meta.as<uint4>();
-  B.totals = ctx->totals.as<uint64_t>();
-  B.slowq_count = (uint32_t*)(B.totals + 4);
-  ctx->have_plan = true;
-  ctx->sampled = false;
-  ctx->results_valid = false;
-  return SG_OK;
+  return finish_plan(ctx, nw, b->n_segs, (uint32_t)slots, b->batch_id, b->first_window, b->first_slot, b->paired, b->name_prefix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1123,6 +1154,170 @@ int sg_gc_percent(sg_ctx* ctx, const sg_gc_window* windows, uint64_t n, int32_t*
   SG_HIP(hipMemcpyAsync(gc_out, ctx->gco.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   SG_HIP(hipStreamSynchronize(ctx->stream));
   return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling plan made on the device
+// ------------------------------------------------------------------------------------------------
+static int check_gens(sg_ctx* ctx, const sg_window_gen* gens, uint64_t n_gens, uint32_t n_segs, uint32_t frag, std::vector<uint64_t>& prefix,
+                      const char* who) {
+  const size_t nch = (size_t)(ctx->B.chain_len - ctx->B.chain_off);
+  std::vector<uint64_t> meta(2 * nch);
+  if (nch) SG_HIP(hipMemcpy(meta.data(), ctx->chain_meta.p, meta.size() * 8, hipMemcpyDeviceToHost));
+  prefix.assign(n_gens + 1, 0);
+  for (uint64_t g = 0; g < n_gens; g++) {
+    const sg_window_gen& G = gens[g];
+    if (G.chain >= nch || G.hap_len == 0 || G.hap_base + G.hap_len > meta[nch + G.chain])
+      return ctx->fail(SG_ERR_INVALID, std::string(who) + ": generator " + std::to_string(g) + " does not lie inside its chain");
+    if (G.seg >= n_segs || (g && G.seg < gens[g - 1].seg)) return ctx->fail(SG_ERR_INVALID, std::string(who) + ": generators must be ordered by segment");
+    prefix[g + 1] = prefix[g] + (G.hap_len + frag - 1) / frag;
+  }
+  return SG_OK;
+}
+
+int sg_windows_build(sg_ctx* ctx, uint32_t store_id, const sg_window_gen* gens, uint64_t n_gens, uint32_t n_segs, const sg_gc_model* model,
+                     double* seg_weight_out, uint64_t* n_windows_out) {
+  if (!ctx || !model || !model->means || !model->quantiles || (n_gens && !gens) || (n_segs && !seg_weight_out)) return SG_ERR_INVALID;
+  if (model->lg_cells < 1 || model->lg_cells > 20 || model->frag_size == 0) return ctx->fail(SG_ERR_INVALID, "sg_windows_build: bad model");
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_windows_build: call sg_upload_haplotypes / sg_build_haplotypes first");
+  SG_HIP(hipSetDevice(ctx->device));
+  std::vector<uint64_t> prefix;
+  if (int rc = check_gens(ctx, gens, n_gens, n_segs, model->frag_size, prefix, "sg_windows_build")) return rc;
+  const uint64_t n = prefix[n_gens];
+  std::vector<uint64_t> seg_first((size_t)n_segs + 1, n);
+  {
+    uint32_t k = 0;
+    for (uint64_t g = 0; g < n_gens; g++)
+      for (; k <= gens[g].seg; k++) seg_first[k] = prefix[g];
+  }
+  if (n_windows_out) *n_windows_out = n;
+  for (uint32_t k = 0; k < n_segs; k++) seg_weight_out[k] = 0.0;
+  DevBuf& store = ctx->wstore[store_id];
+  ctx->wstore_n[store_id] = n;
+  if (!n) return SG_OK;
+  SG_ENSURE(store, n * 8);
+  // work: gens | prefix | seg_first | windows | seg_ord | win_ord | gc | seg sums
+  const size_t cells = (size_t)1 << model->lg_cells;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 63) & ~(size_t)63; return o; };
+  const size_t o_gens = take(n_gens * sizeof(sg_window_gen)), o_pre = take((n_gens + 1) * 8), o_sf = take(((size_t)n_segs + 1) * 8);
+  const size_t o_win = take(n * sizeof(sg_gc_window)), o_so = take(n * 4), o_wo = take(n * 4), o_gc = take(n * 4), o_ss = take((size_t)n_segs * 8);
+  SG_ENSURE(ctx->wwork, off);
+  SG_ENSURE(ctx->gcm, (101 + cells + 1) * 8);
+  uint8_t* wk = ctx->wwork.as<uint8_t>();
+  hipStream_t s = ctx->stream;
+  SG_HIP(hipMemcpyAsync(wk + o_gens, gens, n_gens * sizeof(sg_window_gen), hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(wk + o_pre, prefix.data(), (n_gens + 1) * 8, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(wk + o_sf, seg_first.data(), ((size_t)n_segs + 1) * 8, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(ctx->gcm.p, model->means, 101 * 8, hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(ctx->gcm.as<double>() + 101, model->quantiles, (cells + 1) * 8, hipMemcpyHostToDevice, s));
+  sg::launch_tile((const sg_window_gen*)(wk + o_gens), (const uint64_t*)(wk + o_pre), (uint32_t)n_gens, n, model->frag_size,
+                  (const uint64_t*)(wk + o_sf), (sg_gc_window*)(wk + o_win), (uint32_t*)(wk + o_so), (uint32_t*)(wk + o_wo), s);
+  sg::launch_gc(ctx->B.chains, ctx->B.chain_off, (const sg_gc_window*)(wk + o_win), n, (int32_t*)(wk + o_gc), s);
+  sg::launch_gc_weight((const int32_t*)(wk + o_gc), (const sg_gc_window*)(wk + o_win), (const uint32_t*)(wk + o_so), (const uint32_t*)(wk + o_wo), n,
+                       ctx->gcm.as<double>(), model->std, ctx->gcm.as<double>() + 101, model->lg_cells, model->frag_size,
+                       model->full_tile_form, model->ctx24, ctx->seed, store.as<double>(), s);
+  sg::launch_seg_sum(store.as<double>(), (const uint64_t*)(wk + o_sf), n_segs, (double*)(wk + o_ss), s);
+  SG_HIP(hipGetLastError());
+  SG_HIP(hipMemcpyAsync(seg_weight_out, wk + o_ss, (size_t)n_segs * 8, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  return SG_OK;
+}
+
+void sg_windows_drop(sg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->wstore) kv.second.release();
+  ctx->wstore.clear();
+  ctx->wstore_n.clear();
+}
+
+int sg_plan_windows(sg_ctx* ctx, uint32_t store_id, const sg_window_gen* gens, uint64_t n_gens, const sg_active_seg* active, uint32_t n_active,
+                    uint32_t frag_size, uint32_t batch_id, int32_t paired, const char* name_prefix, uint64_t* slots_out,
+                    uint64_t* n_windows_out) {
+  if (!ctx || (n_gens && !gens) || (n_active && (!active || !slots_out)) || frag_size == 0) return SG_ERR_INVALID;
+  if (!ctx->have_profile) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: call sg_load_profile first");
+  if (!ctx->have_haps) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: no haplotypes on the device");
+  if (batch_id > 0xFFFF) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: batch_id must fit 16 bits");
+  const size_t plen = name_prefix ? strlen(name_prefix) : 0;
+  if (plen == 0 || plen > 990) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: bad name_prefix (1..990 bytes)");
+  auto it = ctx->wstore.find(store_id);
+  if (it == ctx->wstore.end()) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: no window weights under this store id (sg_windows_build)");
+  SG_HIP(hipSetDevice(ctx->device));
+  std::vector<uint64_t> prefix;
+  if (int rc = check_gens(ctx, gens, n_gens, n_active, frag_size, prefix, "sg_plan_windows")) return rc;
+  const uint64_t n = prefix[n_gens], n_store = ctx->wstore_n[store_id];
+  if (n > 0xFFFFFFF0ull) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: more than 2^32 windows in one batch");
+  for (uint64_t g = 0; g < n_gens; g++)
+    if (gens[g].first_window + (prefix[g + 1] - prefix[g]) > n_store)
+      return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: generator " + std::to_string(g) + " points past the stored weights");
+  sg_ctx::PlanInfo& pi = ctx->winfo;
+  pi = sg_ctx::PlanInfo();
+  pi.seg_first.assign((size_t)n_active + 1, (uint32_t)n);
+  {
+    uint32_t k = 0;
+    for (uint64_t g = 0; g < n_gens; g++)
+      for (; k <= gens[g].seg; k++) pi.seg_first[k] = (uint32_t)prefix[g];
+  }
+  for (uint32_t a = 0; a < n_active; a++) {
+    if (active[a].seg_size == 0) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: seg_size 0");
+    if (pi.seg_first[a] == pi.seg_first[a + 1]) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: active segment without windows");
+    pi.seg_size.push_back(active[a].seg_size);
+  }
+  if (n_windows_out) *n_windows_out = n;
+  pi.n_windows = n; pi.n_active = n_active; pi.batch_id = batch_id; pi.paired = paired ? 1 : 0; pi.prefix = name_prefix;
+  pi.slot_first.assign((size_t)n_active + 1, 0);
+  if (n) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 63) & ~(size_t)63; return o; };
+    const size_t o_gens = take(n_gens * sizeof(sg_window_gen)), o_pre = take((n_gens + 1) * 8), o_act = take((size_t)n_active * sizeof(sg_active_seg));
+    const size_t o_sf = take(((size_t)n_active + 1) * 4), o_sum = take((size_t)n_active * 8), o_pl = take(n * 4), o_off = take(n * 8);
+    const size_t o_bs = take(((size_t)sg::scan_blocks((uint32_t)n) + 8) * 8), o_tot = take(8), o_ss = take(((size_t)n_active + 1) * 8);
+    SG_ENSURE(ctx->wwork, off);
+    SG_ENSURE(ctx->wplan, n * sizeof(sg_window));
+    uint8_t* wk = ctx->wwork.as<uint8_t>();
+    hipStream_t s = ctx->stream;
+    SG_HIP(hipMemcpyAsync(wk + o_gens, gens, n_gens * sizeof(sg_window_gen), hipMemcpyHostToDevice, s));
+    SG_HIP(hipMemcpyAsync(wk + o_pre, prefix.data(), (n_gens + 1) * 8, hipMemcpyHostToDevice, s));
+    SG_HIP(hipMemcpyAsync(wk + o_act, active, (size_t)n_active * sizeof(sg_active_seg), hipMemcpyHostToDevice, s));
+    SG_HIP(hipMemcpyAsync(wk + o_sf, pi.seg_first.data(), ((size_t)n_active + 1) * 4, hipMemcpyHostToDevice, s));
+    SG_HIP(hipMemsetAsync(wk + o_sum, 0, (size_t)n_active * 8, s));
+    sg::launch_window_reads((const sg_window_gen*)(wk + o_gens), (const uint64_t*)(wk + o_pre), (uint32_t)n_gens, n, frag_size, it->second.as<double>(),
+                            (const sg_active_seg*)(wk + o_act), (const uint32_t*)(wk + o_sf), n_active, ctx->wplan.as<sg_window>(),
+                            (unsigned long long*)(wk + o_sum), paired, (uint32_t*)(wk + o_pl), s);
+    sg::launch_scan_u32((const uint32_t*)(wk + o_pl), (uint32_t)n, (uint64_t*)(wk + o_bs), (uint64_t*)(wk + o_off), (uint64_t*)(wk + o_tot), s);
+    sg::launch_slot_base(ctx->wplan.as<sg_window>(), n, (const uint64_t*)(wk + o_off), (const uint32_t*)(wk + o_sf), n_active,
+                         (const uint64_t*)(wk + o_tot), (uint64_t*)(wk + o_ss), s);
+    SG_HIP(hipGetLastError());
+    SG_HIP(hipMemcpyAsync(pi.slot_first.data(), wk + o_ss, ((size_t)n_active + 1) * 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipStreamSynchronize(s));
+    if (pi.slot_first[n_active] > 0xFFFFFFF0ull) return ctx->fail(SG_ERR_INVALID, "sg_plan_windows: more than 2^32 fragments in one batch");
+  }
+  for (uint32_t a = 0; a < n_active; a++) slots_out[a] = pi.slot_first[a + 1] - pi.slot_first[a];
+  pi.valid = true;
+  ctx->have_plan = false;
+  return SG_OK;
+}
+
+int sg_plan_range(sg_ctx* ctx, uint32_t a0, uint32_t a1) {
+  if (!ctx) return SG_ERR_INVALID;
+  sg_ctx::PlanInfo& pi = ctx->winfo;
+  if (!pi.valid) return ctx->fail(SG_ERR_INVALID, "sg_plan_range: call sg_plan_windows first");
+  if (a0 >= a1 || a1 > pi.n_active) return ctx->fail(SG_ERR_INVALID, "sg_plan_range: empty or out-of-range run of segments");
+  SG_HIP(hipSetDevice(ctx->device));
+  const uint32_t w_lo = pi.seg_first[a0], w_hi = pi.seg_first[a1], n_segs = a1 - a0;
+  const uint64_t nw = (uint64_t)w_hi - w_lo;
+  const uint64_t slot_lo = pi.slot_first[a0], slots = pi.slot_first[a1] - slot_lo;
+  SG_ENSURE(ctx->windows, (nw + 1) * sizeof(sg_window));
+  SG_ENSURE(ctx->segmeta, ((size_t)n_segs * 2 + 2) * 4);
+  std::vector<uint32_t> segmeta;
+  for (uint32_t a = a0; a < a1; a++) segmeta.push_back(pi.seg_size[a]);
+  for (uint32_t a = a0; a <= a1; a++) segmeta.push_back(pi.seg_first[a] - w_lo);
+  SG_HIP(hipMemcpyAsync(ctx->segmeta.p, segmeta.data(), segmeta.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  sg::launch_slice(ctx->wplan.as<sg_window>(), w_lo, nw, a0, (uint32_t)slot_lo, ctx->windows.as<sg_window>(), ctx->stream);
+  SG_HIP(hipGetLastError());
+  return finish_plan(ctx, nw, n_segs, (uint32_t)slots, pi.batch_id, w_lo, (uint32_t)slot_lo, pi.paired, pi.prefix.c_str());
 }
 
 int sg_window_weights(sg_ctx* ctx, const sg_gc_window* windows, const uint32_t* seg_ord, const uint32_t* win_ord, uint64_t n,

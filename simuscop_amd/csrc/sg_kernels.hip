@@ -1523,6 +1523,105 @@ __global__ __launch_bounds__(256) void gc_weight_kernel(const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// sampling plan on the device (sg_windows_build / sg_plan_windows / sg_plan_range)
+// ------------------------------------------------------------------------------------------------
+// generator of window w: the last one whose prefix (first window) is <= w
+__device__ __forceinline__ uint32_t gen_of(const uint64_t* __restrict__ prefix, uint32_t n_gens, uint64_t w) {
+  uint32_t lo = 0, hi = n_gens - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= w) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// lane = window: geometry of the tile (Segment.cpp:566-590), its segment and its ordinal inside the segment
+__global__ __launch_bounds__(256) void tile_kernel(const sg_window_gen* __restrict__ gens, const uint64_t* __restrict__ prefix,
+                                                   uint32_t n_gens, uint64_t n, uint32_t frag, const uint64_t* __restrict__ seg_first,
+                                                   sg_gc_window* __restrict__ out, uint32_t* __restrict__ seg_ord, uint32_t* __restrict__ win_ord) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const uint32_t g = gen_of(prefix, n_gens, w);
+  const sg_window_gen G = gens[g];
+  const uint64_t t = w - prefix[g], off = t * frag;
+  sg_gc_window o;
+  o.start = G.hap_base + off;
+  o.chain = G.chain;
+  o.len = (uint32_t)(G.hap_len - off < frag ? G.hap_len - off : frag);
+  out[w] = o;
+  seg_ord[w] = G.seg;
+  win_ord[w] = (uint32_t)(w - seg_first[G.seg]);
+}
+// lane = segment: weight sum in window order (the reference's summation order, Segment.cpp:627-630)
+__global__ __launch_bounds__(64) void seg_sum_kernel(const double* __restrict__ wt, const uint64_t* __restrict__ seg_first, uint32_t n_segs,
+                                                     double* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_segs) return;
+  double acc = 0.0;
+  for (uint64_t w = seg_first[k]; w < seg_first[k + 1]; w++) acc = __dadd_rn(acc, wt[w]);
+  out[k] = acc;
+}
+// lane = window of an active segment: fragRCs[i] = (long)(fragWeights[i] * readCount / totalWL), Segment.cpp:466-470
+__global__ __launch_bounds__(256) void window_reads_kernel(const sg_window_gen* __restrict__ gens, const uint64_t* __restrict__ prefix,
+                                                           uint32_t n_gens, uint64_t n, uint32_t frag, const double* __restrict__ wt,
+                                                           const sg_active_seg* __restrict__ act, sg_window* __restrict__ rows,
+                                                           unsigned long long* __restrict__ seg_sum) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const uint32_t g = gen_of(prefix, n_gens, w);
+  const sg_window_gen G = gens[g];
+  const uint64_t t = w - prefix[g], off = t * frag;
+  const sg_active_seg A = act[G.seg];
+  const double total = __dadd_rn(A.weight, 2.2204e-16);
+  const long long rc = (long long)__ddiv_rn(__dmul_rn(wt[G.first_window + t], (double)A.reads), total);
+  sg_window o;
+  o.hap_base = G.hap_base;
+  o.chain = G.chain;
+  o.spos = (uint32_t)off;
+  o.len = (uint32_t)(G.hap_len - off < frag ? G.hap_len - off : frag);
+  o.n_reads = (int32_t)rc;
+  o.seg = G.seg;
+  o.slot_base = 0;
+  rows[w] = o;
+  atomicAdd(seg_sum + G.seg, (unsigned long long)rc);
+}
+// lane = active segment: the remainder goes to the segment's first window (Segment.cpp:472-474)
+__global__ __launch_bounds__(64) void seg_remainder_kernel(const sg_active_seg* __restrict__ act, const uint32_t* __restrict__ seg_first,
+                                                           uint32_t n_act, const unsigned long long* __restrict__ seg_sum,
+                                                           sg_window* __restrict__ rows) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_act) return;
+  const long long sum = (long long)seg_sum[a];
+  if (sum < act[a].reads) rows[seg_first[a]].n_reads += (int32_t)(act[a].reads - sum);
+}
+__global__ __launch_bounds__(256) void planned_kernel(const sg_window* __restrict__ rows, uint64_t n, int32_t paired, uint32_t* __restrict__ planned) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const int32_t r = rows[w].n_reads;
+  planned[w] = r <= 0 ? 0u : (paired ? ((uint32_t)r + 1u) / 2u : (uint32_t)r);
+}
+__global__ __launch_bounds__(256) void slot_base_kernel(sg_window* __restrict__ rows, uint64_t n, const uint64_t* __restrict__ off) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n) rows[w].slot_base = (uint32_t)off[w];
+}
+// planned fragments before each active segment's first window (and the total in [n_act])
+__global__ __launch_bounds__(64) void seg_slots_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ seg_first, uint32_t n_act,
+                                                       const uint64_t* __restrict__ total, uint64_t* __restrict__ out) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < n_act) out[a] = off[seg_first[a]];
+  if (a == n_act) out[a] = *total;
+}
+// rows [w_lo, w_lo + n) of the batch table as a batch of their own: segment ordinals and slots relative to the run
+__global__ __launch_bounds__(256) void slice_kernel(const sg_window* __restrict__ all, uint64_t w_lo, uint64_t n, uint32_t a0, uint32_t slot_lo,
+                                                    sg_window* __restrict__ out) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  sg_window o = all[w_lo + w];
+  o.seg -= a0;
+  o.slot_base -= slot_lo;
+  out[w] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (called from sg_api.cpp through plain C++ declarations)
 // ------------------------------------------------------------------------------------------------
 void launch_plan(const DevProfile& P, const DevBatch& B, hipStream_t s) {
@@ -1667,6 +1766,31 @@ void launch_gc_weight(const int32_t* gc, const sg_gc_window* wins, const uint32_
   if (!n) return;
   hipLaunchKernelGGL(gc_weight_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, gc, wins, seg_ord, win_ord, n, means, std, Q,
                      lg_cells, frag, full_tile_form, KIND_GC | (ctx24 << 8), (uint32_t)seed, (uint32_t)(seed >> 32), out);
+}
+static inline uint32_t blocks256(uint64_t n) { return (uint32_t)((n + 255) / 256); }
+void launch_tile(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_gens, uint64_t n, uint32_t frag, const uint64_t* seg_first,
+                 sg_gc_window* out, uint32_t* seg_ord, uint32_t* win_ord, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(tile_kernel, dim3(blocks256(n)), dim3(256), 0, s, gens, prefix, n_gens, n, frag, seg_first, out, seg_ord, win_ord);
+}
+void launch_seg_sum(const double* wt, const uint64_t* seg_first, uint32_t n_segs, double* out, hipStream_t s) {
+  if (n_segs) hipLaunchKernelGGL(seg_sum_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, s, wt, seg_first, n_segs, out);
+}
+void launch_window_reads(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_gens, uint64_t n, uint32_t frag, const double* wt,
+                         const sg_active_seg* act, const uint32_t* seg_first, uint32_t n_act, sg_window* rows, unsigned long long* seg_sum,
+                         int32_t paired, uint32_t* planned, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(window_reads_kernel, dim3(blocks256(n)), dim3(256), 0, s, gens, prefix, n_gens, n, frag, wt, act, rows, seg_sum);
+  hipLaunchKernelGGL(seg_remainder_kernel, dim3((n_act + 63) / 64), dim3(64), 0, s, act, seg_first, n_act, seg_sum, rows);
+  hipLaunchKernelGGL(planned_kernel, dim3(blocks256(n)), dim3(256), 0, s, rows, n, paired, planned);
+}
+void launch_slot_base(sg_window* rows, uint64_t n, const uint64_t* off, const uint32_t* seg_first, uint32_t n_act, const uint64_t* total,
+                      uint64_t* seg_slots, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(slot_base_kernel, dim3(blocks256(n)), dim3(256), 0, s, rows, n, off);
+  hipLaunchKernelGGL(seg_slots_kernel, dim3((n_act + 64) / 64), dim3(64), 0, s, off, seg_first, n_act, total, seg_slots);
+}
+void launch_slice(const sg_window* all, uint64_t w_lo, uint64_t n, uint32_t a0, uint32_t slot_lo, sg_window* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(slice_kernel, dim3(blocks256(n)), dim3(256), 0, s, all, w_lo, n, a0, slot_lo, out);
 }
 void launch_gc(const uint8_t* chains, const uint64_t* chain_off, const sg_gc_window* wins, uint64_t n, int32_t* out, hipStream_t s) {
   if (!n) return;
