@@ -67,7 +67,7 @@ def main(args):
     fasta, contigs = _genome(args.scale, rank, barrier)
     prof_file, L = bench.PROFILES[args.profile]
     cfg = f"/tmp/simuscop_c3_config_r{rank}.txt"
-    bench.write_config(cfg, fasta, f"/tmp/simuscop_c3_out_r{rank}", coverage=args.coverage, threads=min(16, os.cpu_count() or 1),
+    bench.write_config(cfg, fasta, f"/tmp/simuscop_c3_out_r{rank}", coverage=args.coverage, threads=min(64, os.cpu_count() or 1),
                        profile=prof_file)
     opts = dict(device=local_rank, quiet=1, write_files=0, seed=0x5EED0C3, shard_rank=rank, shard_world=world)
     exchange = None
