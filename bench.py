@@ -341,7 +341,7 @@ def main():
             out["output_seed"] = 0x5EED0000 + rank
         if world == 1 and not args.no_host_pinned:
             try:
-                hs = max(2, min(args.steps, 4))
+                hs = max(2, min(args.steps, 10))   # the first pass of a leg is not overlapped with a drain: more passes, closer to the steady rate
                 out["host_pinned"] = {"plain": host_pinned_rate(sess, hs, False), "gzip": host_pinned_rate(sess, hs, True),
                                       "counts": "pairs whose FASTQ text (plain, or BGZF made on the device) is complete in pinned host "
                                                 "memory, passes drained while the next one is sampled",

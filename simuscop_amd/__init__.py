@@ -126,7 +126,8 @@ def load_engine():
     lib.sg_compress.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.sg_fetch_compressed.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p]
     lib.sg_bgzf_eof.argtypes = [C.c_char_p]
-    lib.sg_deflate_plan.argtypes = [C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
+    lib.sg_deflate_plan.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p,
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
     lib.sg_deflate_plan.restype = C.c_uint32
     lib.sg_detach_outputs.argtypes = [vp, C.POINTER(vp)]
     lib.sg_outputs_sizes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -56,12 +56,14 @@ void launch_pack2(const uint8_t* chains, uint64_t bytes, uint32_t* fwd2, uint32_
 // sg_deflate.hip
 struct DevDeflate {
   const uint8_t* text; uint64_t bytes; uint32_t n_chunks;
-  const uint32_t* code; const uint32_t* prefix; uint32_t prefix_words, prefix_bits;
+  const uint32_t* code; const uint32_t* len_tok; const uint32_t* dist_code;
+  const uint32_t* prefix; uint32_t prefix_words, prefix_bits;
   const uint32_t* crc_tab; const uint32_t* crc_shift; uint32_t crc_init_full, crc_init_last;
-  uint32_t* next; uint32_t* msize; const uint64_t* moff; uint8_t* out;
+  uint32_t* next; uint32_t* msize; const uint64_t* moff;
+  uint4* rec; uint16_t* lbits; unsigned long long* hist; uint8_t* out;
 };
-void launch_gz_hist(const uint8_t* text, uint64_t bytes, unsigned long long* hist, hipStream_t s);
-void launch_gz_size(const void* d, uint32_t n_chunks, hipStream_t s);
+void launch_gz_hist(const void* d, uint32_t n_chunks, hipStream_t s);
+void launch_gz_match(const void* d, uint32_t n_chunks, hipStream_t s);
 void launch_gz_encode(const void* d, uint32_t n_chunks, uint32_t prefix_bits, hipStream_t s);
 void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* out, uint64_t* total, hipStream_t s);
 }  // namespace sg
@@ -623,13 +625,17 @@ int sg_bgzf_eof(uint8_t out[28]) {
   return SG_OK;
 }
 
-uint32_t sg_deflate_plan(const uint64_t counts[256], uint8_t lens[257], uint32_t codes[257], uint32_t* prefix_words, uint32_t cap) {
-  if (!counts || !lens || !codes || !prefix_words) return 0;
+uint32_t sg_deflate_plan(const uint64_t lit_counts[286], const uint64_t dist_counts[30], uint8_t lit_lens[286], uint32_t lit_codes[286],
+                         uint8_t dist_lens[30], uint32_t dist_codes[30], uint32_t len_tokens[65], uint32_t* prefix_words, uint32_t cap) {
+  if (!lit_counts || !dist_counts || !lit_lens || !lit_codes || !dist_lens || !dist_codes || !len_tokens || !prefix_words) return 0;
   sg::DeflatePlan plan;
-  sg::deflate_build_plan(counts, &plan);
+  sg::deflate_build_plan(lit_counts, dist_counts, &plan);
   if (plan.prefix.size() > cap) return 0;
-  memcpy(lens, plan.lit_len, 257);
-  memcpy(codes, plan.lit_code, 257 * 4);
+  memcpy(lit_lens, plan.lit_len, sizeof plan.lit_len);
+  memcpy(lit_codes, plan.lit_code, sizeof plan.lit_code);
+  memcpy(dist_lens, plan.dist_len, sizeof plan.dist_len);
+  memcpy(dist_codes, plan.dist_code, sizeof plan.dist_code);
+  memcpy(len_tokens, plan.len_token, sizeof plan.len_token);
   memcpy(prefix_words, plan.prefix.data(), plan.prefix.size() * 4);
   return plan.prefix_bits;
 }
@@ -647,33 +653,48 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     if (bytes / sg::kGzChunk >= 0xFFFFFFF0ull) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_compress: text too large");
     const uint8_t* text = m == 0 ? ctx->out1.as<uint8_t>() : ctx->out2.as<uint8_t>();
     const uint32_t n_chunks = (uint32_t)((bytes + sg::kGzChunk - 1) / sg::kGzChunk);
-    // work buffer: hist[256] u64 | total u64 | tables | msize[n] u32 | moff[n] u64 | block sums
-    const size_t tab_words = 260 + 1024 + sg::kGzLevels * 32 + 256;  // + prefix (<= 256 words)
-    const size_t off_tab = 2048 + 64, off_msize = off_tab + tab_words * 4;
+    // work buffer: hist[320] u64 | total u64 | counters | tables | msize[n] u32 | moff[n] u64 | block sums | lane bits | records
+    const size_t head = 320 * 8 + 64;
+    const size_t tab_words = 288 + 68 + 32 + 1024 + sg::kGzLevels * 32 + 256;  // + prefix (<= 256 words)
+    const size_t off_tab = head, off_msize = off_tab + tab_words * 4;
     const size_t off_moff = (off_msize + (size_t)n_chunks * 4 + 63) & ~(size_t)63;
     const size_t off_bsum = off_moff + (size_t)n_chunks * 8;
-    SG_ENSURE(ctx->gz_work, off_bsum + ((size_t)sg::scan_blocks(n_chunks) + 8) * 8);
+    const size_t off_lbits = (off_bsum + ((size_t)sg::scan_blocks(n_chunks) + 8) * 8 + 63) & ~(size_t)63;
+    const size_t off_rec = (off_lbits + (size_t)n_chunks * sg::kGzThreads * 2 + 63) & ~(size_t)63;
+    SG_ENSURE(ctx->gz_work, off_rec + (size_t)n_chunks * sg::kGzThreads * 32);
     uint8_t* wk = ctx->gz_work.as<uint8_t>();
-    // 1. sampled histogram -> Huffman code, member prefix, CRC tables (host)
-    SG_HIP(hipMemsetAsync(wk, 0, 2048 + 64, s));
-    sg::launch_gz_hist(text, bytes, (unsigned long long*)wk, s);
+    sg::DevDeflate D;
+    memset(&D, 0, sizeof D);
+    D.text = text; D.bytes = bytes; D.n_chunks = n_chunks;
+    D.hist = (unsigned long long*)wk;
+    D.next = (uint32_t*)(wk + 320 * 8 + 16);  // inside the zeroed head of the work buffer
+    D.msize = (uint32_t*)(wk + off_msize);
+    D.moff = (const uint64_t*)(wk + off_moff);
+    D.lbits = (uint16_t*)(wk + off_lbits);
+    D.rec = (uint4*)(wk + off_rec);
+    // 1. token histogram of every 16th member -> the two Huffman codes, member prefix, CRC tables (host)
+    SG_HIP(hipMemsetAsync(wk, 0, head, s));
+    sg::launch_gz_hist(&D, n_chunks, s);
     SG_HIP(hipGetLastError());
-    uint64_t hist[256];
+    uint64_t hist[320];
     SG_HIP(hipMemcpyAsync(hist, wk, sizeof hist, hipMemcpyDeviceToHost, s));
     SG_HIP(hipStreamSynchronize(s));
     sg::DeflatePlan plan;
-    sg::deflate_build_plan(hist, &plan);
+    sg::deflate_build_plan(hist, hist + 288, &plan);
     if (plan.prefix.size() > 256) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_compress: block header longer than expected");
     std::vector<uint32_t> tab(tab_words, 0);
-    for (int i = 0; i < 257; i++) tab[i] = plan.lit_code[i] | ((uint32_t)plan.lit_len[i] << 16);
-    memcpy(&tab[260], plan.crc_table, sizeof plan.crc_table);
-    memcpy(&tab[260 + 1024], plan.crc_shift, sizeof plan.crc_shift);
-    memcpy(&tab[260 + 1024 + sg::kGzLevels * 32], plan.prefix.data(), plan.prefix.size() * 4);
+    for (int i = 0; i < sg::kGzLitSyms; i++) tab[i] = plan.lit_code[i] | ((uint32_t)plan.lit_len[i] << 16);
+    memcpy(&tab[288], plan.len_token, sizeof plan.len_token);
+    for (int i = 0; i < sg::kGzDistSyms; i++) tab[288 + 68 + i] = plan.dist_code[i] | ((uint32_t)plan.dist_len[i] << 16);
+    const size_t t_crc = 288 + 68 + 32;
+    memcpy(&tab[t_crc], plan.crc_table, sizeof plan.crc_table);
+    memcpy(&tab[t_crc + 1024], plan.crc_shift, sizeof plan.crc_shift);
+    memcpy(&tab[t_crc + 1024 + sg::kGzLevels * 32], plan.prefix.data(), plan.prefix.size() * 4);
     SG_HIP(hipMemcpyAsync(wk + off_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
-    sg::DevDeflate D;
-    D.text = text; D.bytes = bytes; D.n_chunks = n_chunks;
     D.code = (const uint32_t*)(wk + off_tab);
-    D.crc_tab = D.code + 260;
+    D.len_tok = D.code + 288;
+    D.dist_code = D.len_tok + 68;
+    D.crc_tab = D.dist_code + 32;
     D.crc_shift = D.crc_tab + 1024;
     D.prefix = D.crc_shift + sg::kGzLevels * 32;
     D.prefix_words = (uint32_t)plan.prefix.size();
@@ -681,16 +702,12 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     D.crc_init_full = plan.crc_init_full;
     const uint64_t last = bytes - (uint64_t)(n_chunks - 1) * sg::kGzChunk;
     D.crc_init_last = sg::crc_advance(plan, 0xFFFFFFFFu, last);
-    D.next = (uint32_t*)(wk + 2048 + 16);  // inside the zeroed head of the work buffer
-    D.msize = (uint32_t*)(wk + off_msize);
-    D.moff = (const uint64_t*)(wk + off_moff);
-    D.out = nullptr;
-    // 2. member sizes -> offsets
-    sg::launch_gz_size(&D, n_chunks, s);
-    sg::launch_scan_u32(D.msize, n_chunks, (uint64_t*)(wk + off_bsum), (uint64_t*)(wk + off_moff), (uint64_t*)(wk + 2048), s);
+    // 2. tokens, member sizes -> offsets
+    sg::launch_gz_match(&D, n_chunks, s);
+    sg::launch_scan_u32(D.msize, n_chunks, (uint64_t*)(wk + off_bsum), (uint64_t*)(wk + off_moff), (uint64_t*)(wk + 320 * 8), s);
     SG_HIP(hipGetLastError());
     uint64_t total = 0;
-    SG_HIP(hipMemcpyAsync(&total, wk + 2048, 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipMemcpyAsync(&total, wk + 320 * 8, 8, hipMemcpyDeviceToHost, s));
     SG_HIP(hipStreamSynchronize(s));
     DevBuf& gz = m == 0 ? ctx->gz1 : ctx->gz2;
     SG_ENSURE(gz, total + 64);

@@ -93,23 +93,54 @@ struct BitWriter {
 
 }  // namespace
 
+int deflate_length_symbol(uint32_t len, uint32_t* extra_bits, uint32_t* extra_value) {
+  static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  static const uint8_t ebits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  int i = 28;
+  while (i > 0 && base[i] > len) i--;
+  *extra_bits = ebits[i];
+  *extra_value = len - base[i];
+  return i;
+}
+
+int deflate_distance_symbol(uint32_t dist, uint32_t* extra_bits, uint32_t* extra_value) {
+  const uint32_t d = dist - 1u;
+  if (d < 4u) { *extra_bits = 0; *extra_value = 0; return (int)d; }
+  uint32_t lg = 31;
+  while (!(d >> lg)) lg--;
+  *extra_bits = lg - 1u;
+  *extra_value = d & ((1u << (lg - 1u)) - 1u);
+  return (int)(2u * lg + ((d >> (lg - 1u)) & 1u));
+}
+
 uint32_t crc_advance(const DeflatePlan& plan, uint32_t state, uint64_t n) {
   for (uint64_t i = 0; i < n; i++) state = (state >> 8) ^ plan.crc_table[0][state & 0xFFu];
   return state;
 }
 
-void deflate_build_plan(const uint64_t counts[256], DeflatePlan* plan) {
-  // ---- literal / length code: every byte value and end-of-block present ----
-  uint64_t freq[257];
-  uint64_t total = 0;
-  for (int i = 0; i < 256; i++) { freq[i] = counts[i] + 1; total += freq[i]; }
-  freq[256] = std::max<uint64_t>(1, total / kGzChunk);  // one end-of-block per member
-  limited_lengths(freq, 257, 15, plan->lit_len);
-  canonical_codes(plan->lit_len, 257, plan->lit_code);
+void deflate_build_plan(const uint64_t lit_counts[kGzLitSyms], const uint64_t dist_counts[kGzDistSyms], DeflatePlan* plan) {
+  // ---- literal / length code: every byte value, end-of-block and every length symbol present ----
+  uint64_t freq[kGzLitSyms];
+  for (int i = 0; i < kGzLitSyms; i++) freq[i] = lit_counts[i] + 1;  // [256]: one end-of-block per sampled member
+  limited_lengths(freq, kGzLitSyms, 15, plan->lit_len);
+  canonical_codes(plan->lit_len, kGzLitSyms, plan->lit_code);
+  for (uint32_t L = 0; L <= kGzMaxMatch; L++) {
+    plan->len_token[L] = 0;
+    if (L < 3) continue;
+    uint32_t eb, ev;
+    const int sym = 257 + deflate_length_symbol(L, &eb, &ev);
+    const uint32_t nb = plan->lit_len[sym];
+    plan->len_token[L] = (plan->lit_code[sym] | (ev << nb)) | ((nb + eb) << 24);
+  }
+  // ---- distance code: all thirty symbols present ----
+  uint64_t dfreq[kGzDistSyms];
+  for (int i = 0; i < kGzDistSyms; i++) dfreq[i] = dist_counts[i] + 1;
+  limited_lengths(dfreq, kGzDistSyms, 15, plan->dist_len);
+  canonical_codes(plan->dist_len, kGzDistSyms, plan->dist_code);
 
-  // ---- code-length sequence: 257 literal/length lengths + one distance code of zero bits (literals only) ----
-  std::vector<uint8_t> seq(plan->lit_len, plan->lit_len + 257);
-  seq.push_back(0);
+  // ---- code-length sequence: 286 literal/length lengths, then 30 distance lengths (one run-length stream) ----
+  std::vector<uint8_t> seq(plan->lit_len, plan->lit_len + kGzLitSyms);
+  seq.insert(seq.end(), plan->dist_len, plan->dist_len + kGzDistSyms);
   struct Tok { uint8_t sym, extra, extra_bits; };
   std::vector<Tok> toks;
   for (size_t i = 0; i < seq.size();) {
@@ -144,8 +175,8 @@ void deflate_build_plan(const uint64_t counts[256], DeflatePlan* plan) {
   for (uint8_t b : head) bw.put(b, 8);
   bw.put(1, 1);            // BFINAL
   bw.put(2, 2);            // BTYPE = dynamic Huffman
-  bw.put(0, 5);            // HLIT: 257 literal/length codes
-  bw.put(0, 5);            // HDIST: 1 distance code
+  bw.put(kGzLitSyms - 257, 5);  // HLIT: 286 literal/length codes
+  bw.put(kGzDistSyms - 1, 5);   // HDIST: 30 distance codes
   bw.put((uint32_t)(hclen - 4), 4);
   for (int i = 0; i < hclen; i++) bw.put(cl_len[order[i]], 3);
   for (const Tok& t : toks) {

@@ -5,12 +5,23 @@
 // chunk leaves its leading lanes empty), so that the CRC-32 combine tree uses the same nine "advance by
 // 64 * 2^k bytes" operators for every chunk length: leading zero bytes do not change a CRC register
 // that starts at zero.
-//   gz_hist_kernel    byte histogram of a 1/16 sample of the text (the host builds the Huffman code)
-//   gz_size_kernel    sum of code lengths per chunk -> member size (offsets by the u32 -> u64 scan)
-//   gz_encode_kernel  prefix (gzip header + block header), literal codes packed LSB-first through LDS
-//                     (ds_or on 32-bit words), end-of-block, CRC-32, ISIZE; then one contiguous copy out
-// All three are HBM-class passes over the text (4.2 GB per C2 batch); encode adds ~10 integer ops and
-// two LDS operations per byte.
+//
+// Tokens.  The chunk sits in LDS next to a table of 8192 entries that every position's 8-byte gram is
+// hashed into with ds_min: an entry ends up holding the FIRST position of (one of) its grams -- a choice
+// that needs no sequential pass and is the same whatever order the lanes run in.  Each lane then walks
+// its own 64 bytes greedily: at a position it may copy from the table's candidate (reads of one GC window
+// overlap on the template, so most bases of a read were written earlier in the member) or from the
+// previous byte (a run), whichever is longer by the rule of sg_deflate.h; a match ends at the lane's end,
+// and a lane takes at most six.  The walk only visits positions that can start a match (two bit masks made by
+// straight-line code over the lane's 64 bytes), so a wave spends a handful of iterations in it, not 64.  What it
+// yields per lane is a 32-byte record: a bit mask of the match starts and six words (length, distance, bit offset
+// inside the lane's own bit string).
+//   gz_hist_kernel    512 chunks spread over the text: tokens -> histograms of the literal/length and distance symbols
+//                     (the host builds the two Huffman codes from them)
+//   gz_match_kernel   every chunk: tokens -> records, bits per lane, member size (offsets by the u32 -> u64 scan)
+//   gz_encode_kernel  prefix (gzip header + block header); literal codes: one pass over the lane's 64 bytes, the
+//                     bit position jumping over the matches; match codes: one pass over the lane's record; both
+//                     ds_or into a zeroed staging area; end-of-block, CRC-32, ISIZE; one contiguous copy out
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -23,34 +34,27 @@ struct DevDeflate {
   const uint8_t* text;
   uint64_t bytes;
   uint32_t n_chunks;
-  const uint32_t* code;       // [257] reversed code | length << 16
+  const uint32_t* code;       // [288] literal/length: reversed code | length << 16
+  const uint32_t* len_tok;    // [68] length code + extra bits of a match length | bits << 24
+  const uint32_t* dist_code;  // [32] reversed code | length << 16
   const uint32_t* prefix;     // member prefix words (BSIZE = 0)
   uint32_t prefix_words, prefix_bits;
   const uint32_t* crc_tab;    // [4][256]
   const uint32_t* crc_shift;  // [kGzLevels][32]
   uint32_t crc_init_full, crc_init_last;
-  uint32_t* next;             // [2] chunk counter of the encode kernel at [1] (zeroed by the host)
+  uint32_t* next;             // [2] chunk counters of the match / encode kernels (zeroed by the host)
   uint32_t* msize;            // [n_chunks] member bytes
   const uint64_t* moff;       // [n_chunks] member offsets
+  uint4* rec;                 // [n_chunks * 512 * 2] token records
+  uint16_t* lbits;            // [n_chunks * 512] bits of a lane's tokens
+  unsigned long long* hist;   // [320] literal/length counts, then distance counts at 288
   uint8_t* out;
 };
 
-__global__ __launch_bounds__(256) void gz_hist_kernel(const uint8_t* __restrict__ text, uint64_t bytes,
-                                                      unsigned long long* __restrict__ hist) {
-  __shared__ uint32_t h[4][256];
-  for (uint32_t i = threadIdx.x; i < 1024; i += 256) (&h[0][0])[i] = 0;
-  __syncthreads();
-  const uint32_t wv = threadIdx.x >> 6;
-  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 256; i + 16 <= bytes; i += (uint64_t)gridDim.x * 256 * 256) {
-    const uint4 w = *(const uint4*)(text + i);  // i is a multiple of 256
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int k = 0; k < 16; k++) atomicAdd(&h[wv][(ws[k >> 2] >> ((k & 3) * 8)) & 0xFFu], 1u);
-  }
-  __syncthreads();
-  const uint32_t s = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
-  if (s) atomicAdd(&hist[threadIdx.x], (unsigned long long)s);
-}
+constexpr uint32_t kGzTab = 1u << kGzHashBits;
+// members sampled for the token histogram: every stride-th, at most kGzSamples of them
+__host__ __device__ inline uint32_t gz_sample_stride(uint32_t n_chunks) { return (n_chunks + kGzSamples - 1u) / kGzSamples; }
+constexpr uint32_t kGzTxtPad = 32;  // readable zero bytes past the chunk
 
 // the lane's 64 input bytes as 16 words (bytes before the chunk start read as 0); returns the number of
 // leading bytes that are not data
@@ -97,23 +101,285 @@ __device__ __forceinline__ uint32_t gz_block_scan(uint32_t v, uint32_t* wave_tot
   return base + incl - v;
 }
 
-__global__ __launch_bounds__(kGzThreads) void gz_size_kernel(DevDeflate D) {
-  __shared__ uint32_t code[257];
-  __shared__ uint32_t wave_tot[kGzThreads / 64];
-  for (uint32_t i = threadIdx.x; i < 257; i += kGzThreads) code[i] = D.code[i];
+__device__ __forceinline__ uint64_t gz_lds64(const uint8_t* p) {  // unaligned (ds_read_b64 takes any address on gfx950)
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+// table slot (top bits) and tag (low bits) of an 8-byte gram
+__device__ __forceinline__ uint32_t gz_hash(uint32_t lo, uint32_t hi) { return (lo * 0x9E3779B1u + hi) * 0x85EBCA77u; }
+constexpr uint32_t kGzTagBits = 32u - 15u;  // entry = position << 17 | tag
+
+// number of leading bytes on which the text at a and at b agrees, at most `cap` (16 bytes per step)
+__device__ __forceinline__ uint32_t gz_extend(const uint8_t* txt, uint32_t a, uint32_t b, uint32_t cap) {
+  uint32_t l = 0;
+#pragma unroll 1
+  while (l < cap) {
+    struct V { uint64_t lo, hi; } x, y;
+    __builtin_memcpy(&x, txt + a + l, 16);
+    __builtin_memcpy(&y, txt + b + l, 16);
+    const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
+    if (d0 | d1) {
+      l += d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u + ((uint32_t)__builtin_ctzll(d1) >> 3);
+      break;
+    }
+    l += 16u;
+  }
+  return l < cap ? l : cap;
+}
+
+__device__ __forceinline__ uint32_t gz_dist_symbol(uint32_t d1, uint32_t* eb) {  // d1 = distance - 1
+  if (d1 < 4u) { *eb = 0; return d1; }
+  const uint32_t lg = 31u - (uint32_t)__builtin_clz(d1);
+  *eb = lg - 1u;
+  return 2u * lg + ((d1 >> (lg - 1u)) & 1u);
+}
+__device__ __forceinline__ uint32_t gz_len_symbol(uint32_t len) {  // 3..64 -> 257..
+  const uint32_t l3 = len - 3u;
+  if (l3 < 8u) return 257u + l3;
+  const uint32_t lg = 31u - (uint32_t)__builtin_clz(l3);
+  return 257u + 4u * lg - 4u + ((l3 >> (lg - 2u)) & 3u);
+}
+
+// The gram at the lane's byte k (static): low and high half, from the lane's words and the next lane's first two
+#define GZ_GRAM(k, w, nx0, nx1, lo, hi)                                                                              \
+  const uint32_t d_ = (k) >> 2, b_ = (k)&3u;                                                                         \
+  const uint32_t e0_ = w[d_], e1_ = d_ + 1 < 16 ? w[d_ + 1 < 16 ? d_ + 1 : 0] : nx0,                                 \
+                 e2_ = d_ + 2 < 16 ? w[d_ + 2 < 16 ? d_ + 2 : 0] : (d_ + 2 == 16 ? nx0 : nx1);                       \
+  const uint32_t lo = b_ ? __builtin_amdgcn_alignbyte(e1_, e0_, b_) : e0_;                                           \
+  const uint32_t hi = b_ ? __builtin_amdgcn_alignbyte(e2_, e1_, b_) : e1_;
+
+// What a lane's walk yields: where its matches start, what they cover, their lengths / distances and token bits
+struct GzLane {
+  uint32_t first;                // leading bytes of the lane that are not data
+  uint64_t starts, cover;        // bit k: a match starts at / covers the lane's byte k
+  uint32_t mw[kGzLaneMatches];   // length - 3 | (distance - 1) << 6 | 1 << 31, in text order
+  uint32_t w[16];                // the lane's 64 bytes
+};
+
+// Chunk -> LDS (text frame of 32 KB aligned to the chunk's end, first-occurrence table), then the lane's greedy walk.
+// Frame position of the lane's byte k: 64 * lane + k; data starts at kGzChunk - n.
+//   1. the gram at every EVEN data position -> table slot by ds_min (entry = position << 17 | tag): a copy whose source
+//      starts at an odd position is found one byte later, for half the inserts and a table half as crowded; a bit per
+//      position whose five bytes from the previous one on are equal (a run of >= 4 can start there)
+//   2. a bit per position whose slot holds an EARLIER position of the same tag (a candidate to copy from)
+//   3. the walk visits only positions with one of the two bits: everything else is a literal whatever the walk does
+// FULL: a chunk of kGzChunk bytes (all but a text's last): every lane byte is data, no predicates in 1 and 2.
+// (Grams that reach past the chunk's end take zero bytes from the padding; they sit in the chunk's last seven
+// positions, where no match of eight bytes has room, so what they leave in the table is never used.)
+template <bool FULL>
+__device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint32_t n, uint8_t* txt, uint32_t* tab, GzLane& L) {
+  uint32_t lane = threadIdx.x;
+  // (opaque per call: otherwise the 64 "position << 17" constants of the unrolled loops below are hoisted out of the
+  // kernels' chunk loops and live -- spilled -- across them)
+  asm volatile("" : "+v"(lane));
+  uint32_t (&w)[16] = L.w;
+  uint32_t first = 0;
+  if (FULL) __builtin_memcpy(w, D.text + (uint64_t)c * kGzChunk + 64u * lane, 64);
+  else first = gz_load_lane(D, c, lane, n, w);
+  L.first = first;
+#pragma unroll
+  for (int k = 0; k < 4; k++) ((uint4*)(txt + 64u * lane))[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+  if (lane < kGzTxtPad / 4u) ((uint32_t*)(txt + kGzChunk))[lane] = 0;
+  for (uint32_t i = lane; i < kGzTab + 1u; i += kGzThreads) tab[i] = 0xFFFFFFFFu;  // [kGzTab]: where positions before the data go
   __syncthreads();
-  for (uint32_t c = blockIdx.x; c < D.n_chunks; c += gridDim.x) {
+  const uint32_t nx0 = lane + 1u < kGzThreads ? ((const uint32_t*)(txt + 64u * (lane + 1u)))[0] : 0u;
+  const uint32_t nx1 = lane + 1u < kGzThreads ? ((const uint32_t*)(txt + 64u * (lane + 1u)))[1] : 0u;
+  const uint32_t pv = lane ? ((const uint32_t*)(txt + 64u * lane))[-1] : 0u;  // the four bytes before the lane
+  const uint32_t q0 = kGzChunk - n;
+  const int run_from = (int)q0 - (int)(64u * lane);  // a run needs a previous DATA byte: k > run_from
+  uint32_t run_lo = 0, run_hi = 0, cand_lo = 0, cand_hi = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kGzLaneBytes; k++) {
+    GZ_GRAM(k, w, nx0, nx1, lo, hi)
+    if ((k & 1u) == 0u) {
+      const uint32_t q = 64u * lane + k;
+      const uint32_t h = gz_hash(lo, hi);
+      const uint32_t slot = h >> (32u - kGzHashBits);
+      atomicMin(&tab[FULL ? slot : (k >= first ? slot : kGzTab)], (q << kGzTagBits) | (h & ((1u << kGzTagBits) - 1u)));
+    }
+    // bytes k-1 .. k+2 against bytes k .. k+3
+    uint32_t pm1;  // the word at byte k - 1
+    if (k == 0) pm1 = __builtin_amdgcn_alignbyte(w[0], pv, 3);
+    else {
+      const uint32_t dk = (k - 1) >> 2, bk = (k - 1) & 3u;
+      const uint32_t f0 = w[dk], f1 = dk + 1 < 16 ? w[dk + 1 < 16 ? dk + 1 : 0] : nx0;
+      pm1 = bk ? __builtin_amdgcn_alignbyte(f1, f0, bk) : f0;
+    }
+    uint32_t rs = (uint32_t)(pm1 == lo);
+    if (!FULL) rs &= (uint32_t)((int)k > run_from);
+    else if (k == 0) rs &= (uint32_t)(lane != 0u);
+    if (k < 32) run_lo |= rs << (k & 31u);
+    else run_hi |= rs << (k & 31u);
+    if ((k & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);  // (64 independent chains: left alone the scheduler overlaps them all and spills)
+  }
+  __syncthreads();
+  {
+    // (the words again, from LDS: held in registers across the barrier together with the 64 grams made from them the
+    // kernel would need 256 registers and spill)
+    uint32_t v[16];
+    uint32_t lane2 = lane, n0 = nx0, n1 = nx1, first2 = first;  // nothing of the first pass is worth keeping
+    asm volatile("" : "+v"(lane2), "+v"(n0), "+v"(n1), "+v"(first2));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 t = ((const uint4*)(txt + 64u * lane2))[k];
+      v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kGzLaneBytes; k++) {
+      GZ_GRAM(k, v, n0, n1, lo, hi)
+      const uint32_t q = 64u * lane2 + k;
+      const uint32_t h = gz_hash(lo, hi);
+      const uint32_t e = tab[h >> (32u - kGzHashBits)];
+      // same tag, earlier position: the entry is smaller than what this position's own would be
+      uint32_t hit = (uint32_t)(e < ((q << kGzTagBits) | (h & ((1u << kGzTagBits) - 1u)))) & (uint32_t)(((e ^ h) & ((1u << kGzTagBits) - 1u)) == 0u);
+      if (!FULL) hit &= (uint32_t)(k >= first2);
+      if (k < 32) cand_lo |= hit << (k & 31u);
+      else cand_hi |= hit << (k & 31u);
+      if ((k & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const uint64_t runm = ((uint64_t)run_hi << 32) | run_lo, cand = ((uint64_t)cand_hi << 32) | cand_lo;
+  uint32_t nm = 0;
+  uint64_t todo = (runm | cand) & ~((first >= 64u ? ~0ull : (1ull << first) - 1ull));
+  L.starts = 0;
+  L.cover = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < kGzLaneMatches; j++) L.mw[j] = 0;
+#pragma unroll 1
+  while (todo != 0ull && nm < kGzLaneMatches) {
+    const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const uint32_t q = 64u * lane + k, room = kGzLaneBytes - k;
+    const uint64_t own = gz_lds64(txt + q);
+    // the first eight bytes of both sources decide which one is followed: the table's candidate if its gram really is
+    // this position's (tags can collide) and the run is shorter than eight; else the run
+    const bool is_run = (runm >> k) & 1ull, is_cand = (cand >> k) & 1ull;
+    uint32_t cq = q - 1u;
+    if (is_cand) {
+      const uint32_t h = gz_hash((uint32_t)own, (uint32_t)(own >> 32));
+      cq = tab[h >> (32u - kGzHashBits)] >> kGzTagBits;
+    }
+    const uint64_t xr = is_run ? gz_lds64(txt + q - 1u) ^ own : 1ull;
+    const uint64_t xh = is_cand && cq < q ? gz_lds64(txt + cq) ^ own : 1ull;
+    const bool take_gram = xh == 0ull && xr != 0ull;
+    uint32_t src = take_gram ? cq : q - 1u;
+    uint32_t len = take_gram ? 8u : (xr ? (uint32_t)__builtin_ctzll(xr) >> 3 : 8u);
+    if (len == 8u && room > 8u) len += gz_extend(txt, src + 8u, q + 8u, room - 8u);
+    len = len < room ? len : room;
+    if (len < (take_gram ? kGzMinGramMatch : kGzMinRun)) len = 0;
+    const uint32_t d1 = q - src - 1u;
+    if (len) {
+      const uint32_t v = (len - 3u) | (d1 << 6) | 0x80000000u;
+#pragma unroll
+      for (uint32_t z = 0; z < kGzLaneMatches; z++)
+        if (z == nm) L.mw[z] = v;
+      nm++;
+      L.starts |= 1ull << k;
+      const uint64_t span = (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << k;
+      L.cover |= span;
+      todo &= ~span;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kGzThreads, 4) void gz_hist_kernel(DevDeflate D) {
+  extern __shared__ uint32_t gz_smem[];
+  uint32_t* tab = gz_smem;                                  // [kGzTab]
+  uint8_t* txt = (uint8_t*)(tab + kGzTab + 4);              // [kGzChunk + pad]
+  uint32_t* h = (uint32_t*)(txt + kGzChunk + kGzTxtPad);    // [320]
+  for (uint32_t i = threadIdx.x; i < 320u; i += kGzThreads) h[i] = 0;
+  const uint32_t stride = gz_sample_stride(D.n_chunks);
+  const uint32_t n_samples = (D.n_chunks + stride - 1u) / stride;
+  for (uint32_t sidx = blockIdx.x; sidx < n_samples; sidx += gridDim.x) {
+    const uint32_t c = sidx * stride;
     const uint64_t left = D.bytes - (uint64_t)c * kGzChunk;
     const uint32_t n = left < kGzChunk ? (uint32_t)left : kGzChunk;
-    uint32_t w[16];
-    const uint32_t first = gz_load_lane(D, c, threadIdx.x, n, w);
-    uint32_t bits = 0;
+    GzLane L;
+    if (n == kGzChunk) gz_tokens<true>(D, c, n, txt, tab, L);
+    else gz_tokens<false>(D, c, n, txt, tab, L);
+#pragma unroll
+    for (uint32_t j = 0; j < kGzLaneMatches; j++) {
+      const uint32_t v = L.mw[j];
+      if (v >> 31) {
+        uint32_t eb;
+        atomicAdd(&h[gz_len_symbol((v & 63u) + 3u)], 1u);
+        atomicAdd(&h[288u + gz_dist_symbol((v >> 6) & 0x7FFFu, &eb)], 1u);
+      }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kGzLaneBytes; k++)
-      if (k >= first) bits += code[(w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu] >> 16;
+      atomicAdd(&h[(k >= L.first && !((L.cover >> k) & 1ull)) ? (L.w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu : 287u], 1u);  // [287]: unused slot
+    if (threadIdx.x == 0) atomicAdd(&h[256], 1u);
+    __syncthreads();
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 320u; i += kGzThreads)
+    if (h[i]) atomicAdd(&D.hist[i], (unsigned long long)h[i]);
+}
+
+__global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
+  extern __shared__ uint32_t gz_smem[];
+  uint32_t* tab = gz_smem;                                  // [kGzTab]
+  uint8_t* txt = (uint8_t*)(tab + kGzTab + 4);              // [kGzChunk + pad]
+  uint32_t* code = (uint32_t*)(txt + kGzChunk + kGzTxtPad); // [288] literal/length, [68] length tokens, [32] distance
+  uint32_t* len_tok = code + 288;
+  uint32_t* dist_code = len_tok + 68;
+  uint32_t* wave_tot = dist_code + 32;                      // [8]
+  __shared__ uint32_t next_c;
+  for (uint32_t i = threadIdx.x; i < 288u; i += kGzThreads) code[i] = D.code[i];
+  for (uint32_t i = threadIdx.x; i < 68u; i += kGzThreads) len_tok[i] = D.len_tok[i];
+  for (uint32_t i = threadIdx.x; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
+  __syncthreads();
+  for (uint32_t c = blockIdx.x; c < D.n_chunks;) {
+    const uint64_t left = D.bytes - (uint64_t)c * kGzChunk;
+    const uint32_t n = left < kGzChunk ? (uint32_t)left : kGzChunk;
+    GzLane L;
+    if (n == kGzChunk) gz_tokens<true>(D, c, n, txt, tab, L);
+    else gz_tokens<false>(D, c, n, txt, tab, L);
+    // bits of the matches, in order, one byte each
+    uint64_t jumps = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kGzLaneMatches; j++) {
+      const uint32_t v = L.mw[j];
+      if (v >> 31) {
+        uint32_t eb;
+        const uint32_t ds = gz_dist_symbol((v >> 6) & 0x7FFFu, &eb);
+        jumps |= (uint64_t)((len_tok[(v & 63u) + 3u] >> 24) + (dist_code[ds] >> 16) + eb) << (8u * j);
+      }
+    }
+    // one pass over the lane's bytes: code lengths of the literals; the bit offset at which each match starts (ten bits
+    // each, shifted in from the top: the first match ends up lowest)
+    uint32_t bits = 0;
+    uint64_t offs = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kGzLaneBytes; k++) {
+      const bool st = (L.starts >> k) & 1ull;
+      offs = st ? (offs >> 10) | ((uint64_t)bits << 50) : offs;
+      bits += st ? (uint32_t)jumps & 0xFFu : 0u;
+      jumps = st ? jumps >> 8 : jumps;
+      const uint32_t cl = code[(L.w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu] >> 16;
+      bits += (k >= L.first && !((L.cover >> k) & 1ull)) ? cl : 0u;
+    }
+    const uint32_t nm = (uint32_t)__popcll(L.starts);
+    offs = nm ? offs >> (10u * (kGzLaneMatches - nm)) : 0ull;
+    uint32_t mw[kGzLaneMatches];
+#pragma unroll
+    for (uint32_t j = 0; j < kGzLaneMatches; j++) mw[j] = L.mw[j] | ((uint32_t)((offs >> (10u * j)) & 0x3FFu) << 21);
+    // record: the start mask and six words (length - 3 | distance - 1 << 6 | bit offset in the lane << 21 | 1 << 31)
+    uint4* rec = D.rec + ((size_t)c * kGzThreads + threadIdx.x) * 2;
+    rec[0] = make_uint4((uint32_t)L.starts, (uint32_t)(L.starts >> 32), mw[0], mw[1]);
+    rec[1] = make_uint4(mw[2], mw[3], mw[4], mw[5]);
+    D.lbits[(size_t)c * kGzThreads + threadIdx.x] = (uint16_t)bits;
     uint32_t total;
     gz_block_scan(bits, wave_tot, &total);
-    if (threadIdx.x == 0) D.msize[c] = (D.prefix_bits + total + (code[256] >> 16) + 7u) / 8u + 8u;
+    if (threadIdx.x == 0) {
+      D.msize[c] = (D.prefix_bits + total + (code[256] >> 16) + 7u) / 8u + 8u;
+      next_c = gridDim.x + atomicAdd(D.next, 1u);
+    }
+    __syncthreads();
+    c = next_c;
     __syncthreads();
   }
 }
@@ -121,13 +387,17 @@ __global__ __launch_bounds__(kGzThreads) void gz_size_kernel(DevDeflate D) {
 __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uint32_t stage_words) {
   extern __shared__ uint32_t gz_smem[];
   uint32_t* stage = gz_smem;                       // [stage_words]
-  uint32_t* code = stage + stage_words;            // [257] (+3 pad)
-  uint32_t* crc_tab = code + 260;                  // [4][256]
+  uint32_t* code = stage + stage_words;            // [288]
+  uint32_t* len_tok = code + 288;                  // [68]
+  uint32_t* dist_code = len_tok + 68;              // [32]
+  uint32_t* crc_tab = dist_code + 32;              // [4][256]
   uint32_t* crc_shift = crc_tab + 1024;            // [kGzLevels][32]
   uint32_t* crcs = crc_shift + kGzLevels * 32;     // [kGzThreads]
   uint32_t* wave_tot = crcs + kGzThreads;          // [8]
   const uint32_t lane = threadIdx.x;
-  for (uint32_t i = lane; i < 257; i += kGzThreads) code[i] = D.code[i];
+  for (uint32_t i = lane; i < 288u; i += kGzThreads) code[i] = D.code[i];
+  for (uint32_t i = lane; i < 68u; i += kGzThreads) len_tok[i] = D.len_tok[i];
+  for (uint32_t i = lane; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
   for (uint32_t i = lane; i < 1024; i += kGzThreads) crc_tab[i] = D.crc_tab[i];
   for (uint32_t i = lane; i < kGzLevels * 32; i += kGzThreads) crc_shift[i] = D.crc_shift[i];
   __syncthreads();
@@ -141,43 +411,65 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
     for (uint32_t i = lane; i < out_words; i += kGzThreads) stage[i] = 0;
     uint32_t w[16];
     const uint32_t first = gz_load_lane(D, c, lane, n, w);
-    // ---- bit offsets ----
-    uint32_t bits = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kGzLaneBytes; k++)
-      if (k >= first) bits += code[(w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu] >> 16;
+    const uint4* rec = D.rec + ((size_t)c * kGzThreads + lane) * 2;
+    const uint4 ra = rec[0], rb = rec[1];
+    const uint32_t bits = D.lbits[(size_t)c * kGzThreads + lane];
     uint32_t total;
     const uint32_t excl = gz_block_scan(bits, wave_tot, &total);  // its barrier also orders the zeroing above
+    const uint32_t base = D.prefix_bits + excl;
     // ---- prefix, BSIZE ----
     if (lane < D.prefix_words) atomicOr(&stage[lane], D.prefix[lane]);
     if (lane == 0) atomicOr(&stage[4], (msize - 1u) & 0xFFFFu);  // bytes 16-17 of the member
-    // ---- literal codes ----
+    // ---- the lane's matches: codes at base + their recorded offset; the bytes they cover; their bit counts ----
+    const uint64_t starts = ((uint64_t)ra.y << 32) | ra.x;
+    uint64_t cover = 0, jumps = 0, st = starts;
     {
-      uint32_t pos = D.prefix_bits + excl;
-      uint32_t wi = pos >> 5;
-      uint32_t nacc = pos & 31u;
-      uint64_t acc = 0;
+      const uint32_t mws[kGzLaneMatches] = {ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
-      for (uint32_t k = 0; k < kGzLaneBytes; k++) {
-        if (k >= first) {
-          const uint32_t e = code[(w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu];
-          acc |= (uint64_t)(e & 0xFFFFu) << nacc;
-          nacc += e >> 16;
-          if (nacc >= 32u) {
-            atomicOr(&stage[wi++], (uint32_t)acc);
-            acc >>= 32;
-            nacc -= 32u;
-          }
+      for (uint32_t j = 0; j < kGzLaneMatches; j++) {
+        const uint32_t v = mws[j];
+        if (v >> 31) {
+          const uint32_t len = (v & 63u) + 3u, d1 = (v >> 6) & 0x7FFFu, off = (v >> 21) & 0x3FFu;
+          const uint32_t s = (uint32_t)__builtin_ctzll(st);
+          st &= st - 1ull;
+          cover |= (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << s;
+          uint32_t eb;
+          const uint32_t ds = gz_dist_symbol(d1, &eb);
+          const uint32_t lt = len_tok[len], dc = dist_code[ds];
+          const uint32_t n1 = lt >> 24, n2 = dc >> 16;
+          const uint64_t tok = (uint64_t)(lt & 0xFFFFFFu) | ((uint64_t)(dc & 0xFFFFu) << n1) | ((uint64_t)(d1 & ((1u << eb) - 1u)) << (n1 + n2));
+          const uint32_t nb = n1 + n2 + eb;  // <= 48
+          jumps |= (uint64_t)nb << (8u * j);
+          const uint32_t pos = base + off, wi = pos >> 5, sh = pos & 31u;
+          const uint64_t lo = tok << sh;
+          atomicOr(&stage[wi], (uint32_t)lo);
+          if (sh + nb > 32u) atomicOr(&stage[wi + 1u], (uint32_t)(lo >> 32));
+          if (sh + nb > 64u) atomicOr(&stage[wi + 2u], (uint32_t)(tok >> (64u - sh)));
         }
       }
-      if (lane == kGzThreads - 1u) {  // end-of-block after the chunk's last byte
-        const uint32_t e = code[256];
-        acc |= (uint64_t)(e & 0xFFFFu) << nacc;
-        nacc += e >> 16;
+    }
+    // ---- literal codes: every byte no match covers, the bit position stepping over the matches ----
+    {
+      uint32_t pos = base;
+#pragma unroll
+      for (uint32_t k = 0; k < kGzLaneBytes; k++) {
+        if ((starts >> k) & 1ull) {
+          pos += (uint32_t)jumps & 0xFFu;
+          jumps >>= 8;
+        }
+        if (k >= first && !((cover >> k) & 1ull)) {
+          const uint32_t e = code[(w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu];
+          const uint32_t cb = e & 0xFFFFu, nb = e >> 16, wi = pos >> 5, sh = pos & 31u;
+          atomicOr(&stage[wi], cb << sh);
+          if (sh + nb > 32u) atomicOr(&stage[wi + 1u], cb >> (32u - sh));
+          pos += nb;
+        }
       }
-      if (nacc) {
-        atomicOr(&stage[wi], (uint32_t)acc);
-        if (nacc > 32u) atomicOr(&stage[wi + 1u], (uint32_t)(acc >> 32));
+      if (lane == kGzThreads - 1u) {  // end-of-block after the chunk's last token
+        const uint32_t e = code[256];
+        const uint32_t cb = e & 0xFFFFu, nb = e >> 16, wi = pos >> 5, sh = pos & 31u;
+        atomicOr(&stage[wi], cb << sh);
+        if (sh + nb > 32u) atomicOr(&stage[wi + 1u], cb >> (32u - sh));
       }
     }
     // ---- CRC-32 of the chunk ----
@@ -228,24 +520,29 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
-void launch_gz_hist(const uint8_t* text, uint64_t bytes, unsigned long long* hist, hipStream_t s) {
-  uint64_t blocks = (bytes / 256 + 255) / 256;
-  if (blocks < 1) blocks = 1;
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(gz_hist_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, text, bytes, hist);
+static size_t gz_token_lds() { return ((size_t)kGzTab + 4 + 288 + 68 + 32 + 8 + 64) * 4 + kGzChunk + kGzTxtPad; }
+void launch_gz_hist(const void* d, uint32_t n_chunks, hipStream_t s) {
+  if (!n_chunks) return;
+  const size_t lds = gz_token_lds();
+  (void)hipFuncSetAttribute((const void*)gz_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t stride = gz_sample_stride(n_chunks);
+  const uint32_t grid = (n_chunks + stride - 1u) / stride;  // <= kGzSamples: one workgroup each, one round on 256 CUs
+  hipLaunchKernelGGL(gz_hist_kernel, dim3(grid), dim3(kGzThreads), lds, s, *(const DevDeflate*)d);
 }
-uint32_t gz_stage_words(uint32_t prefix_bits) {  // worst case: every literal 15 bits
+uint32_t gz_stage_words(uint32_t prefix_bits) {  // worst case: 15 bits per byte (a match token is <= 48 bits for >= 4 bytes)
   return ((prefix_bits + 15u * kGzChunk + 15u + 7u) / 8u + 8u + 3u) / 4u + 4u;
 }
-void launch_gz_size(const void* d, uint32_t n_chunks, hipStream_t s) {
+void launch_gz_match(const void* d, uint32_t n_chunks, hipStream_t s) {
   if (!n_chunks) return;
-  const uint32_t grid = n_chunks < 256u * 16u ? n_chunks : 256u * 16u;
-  hipLaunchKernelGGL(gz_size_kernel, dim3(grid), dim3(kGzThreads), 0, s, *(const DevDeflate*)d);
+  const size_t lds = gz_token_lds();
+  (void)hipFuncSetAttribute((const void*)gz_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t grid = n_chunks < 512u ? n_chunks : 512u;  // two workgroups per CU fit in LDS
+  hipLaunchKernelGGL(gz_match_kernel, dim3(grid), dim3(kGzThreads), lds, s, *(const DevDeflate*)d);
 }
 void launch_gz_encode(const void* d, uint32_t n_chunks, uint32_t prefix_bits, hipStream_t s) {
   if (!n_chunks) return;
   const uint32_t sw = gz_stage_words(prefix_bits);
-  const size_t lds = ((size_t)sw + 260 + 1024 + kGzLevels * 32 + kGzThreads + 8) * 4;
+  const size_t lds = ((size_t)sw + 288 + 68 + 32 + 1024 + kGzLevels * 32 + kGzThreads + 8) * 4;
   (void)hipFuncSetAttribute((const void*)gz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const uint32_t grid = n_chunks < 512u ? n_chunks : 512u;  // two workgroups per CU fit in LDS
   hipLaunchKernelGGL(gz_encode_kernel, dim3(grid), dim3(kGzThreads), lds, s, *(const DevDeflate*)d, sw);
