@@ -655,7 +655,7 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     const uint32_t n_chunks = (uint32_t)((bytes + sg::kGzChunk - 1) / sg::kGzChunk);
     // work buffer: hist[320] u64 | total u64 | counters | tables | msize[n] u32 | moff[n] u64 | block sums | lane bits | records
     const size_t head = 320 * 8 + 64;
-    const size_t tab_words = 288 + 68 + 32 + 1024 + sg::kGzLevels * 32 + 256;  // + prefix (<= 256 words)
+    const size_t tab_words = 288 + 68 + 32 + 1024 + sg::kGzLevels * 128 + 256;  // + prefix (<= 256 words)
     const size_t off_tab = head, off_msize = off_tab + tab_words * 4;
     const size_t off_moff = (off_msize + (size_t)n_chunks * 4 + 63) & ~(size_t)63;
     const size_t off_bsum = off_moff + (size_t)n_chunks * 8;
@@ -689,14 +689,14 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     const size_t t_crc = 288 + 68 + 32;
     memcpy(&tab[t_crc], plan.crc_table, sizeof plan.crc_table);
     memcpy(&tab[t_crc + 1024], plan.crc_shift, sizeof plan.crc_shift);
-    memcpy(&tab[t_crc + 1024 + sg::kGzLevels * 32], plan.prefix.data(), plan.prefix.size() * 4);
+    memcpy(&tab[t_crc + 1024 + sg::kGzLevels * 128], plan.prefix.data(), plan.prefix.size() * 4);
     SG_HIP(hipMemcpyAsync(wk + off_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     D.code = (const uint32_t*)(wk + off_tab);
     D.len_tok = D.code + 288;
     D.dist_code = D.len_tok + 68;
     D.crc_tab = D.dist_code + 32;
     D.crc_shift = D.crc_tab + 1024;
-    D.prefix = D.crc_shift + sg::kGzLevels * 32;
+    D.prefix = D.crc_shift + sg::kGzLevels * 128;
     D.prefix_words = (uint32_t)plan.prefix.size();
     D.prefix_bits = plan.prefix_bits;
     D.crc_init_full = plan.crc_init_full;

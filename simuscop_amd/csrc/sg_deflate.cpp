@@ -195,8 +195,17 @@ void deflate_build_plan(const uint64_t lit_counts[kGzLitSyms], const uint64_t di
   for (uint32_t i = 0; i < 256; i++)
     for (int t = 1; t < 4; t++)
       plan->crc_table[t][i] = (plan->crc_table[t - 1][i] >> 8) ^ plan->crc_table[0][plan->crc_table[t - 1][i] & 0xFFu];
-  for (uint32_t k = 0; k < kGzLevels; k++)
-    for (int j = 0; j < 32; j++) plan->crc_shift[k][j] = crc_advance(*plan, 1u << j, (uint64_t)kGzLaneBytes << k);
+  for (uint32_t k = 0; k < kGzLevels; k++) {
+    uint32_t col[32];  // the operator is linear over GF(2): its value on a nibble is the xor of its columns
+    for (int j = 0; j < 32; j++) col[j] = crc_advance(*plan, 1u << j, (uint64_t)kGzLaneBytes << k);
+    for (int i = 0; i < 8; i++)
+      for (uint32_t v = 0; v < 16; v++) {
+        uint32_t r = 0;
+        for (int b = 0; b < 4; b++)
+          if ((v >> b) & 1u) r ^= col[4 * i + b];
+        plan->crc_shift[k][i][v] = r;
+      }
+  }
   plan->crc_init_full = crc_advance(*plan, 0xFFFFFFFFu, kGzChunk);
 }
 

@@ -49,7 +49,7 @@ struct DeflatePlan {
   uint32_t prefix_bits = 0;
   // CRC-32 machinery (reflected polynomial 0xEDB88320)
   uint32_t crc_table[4][256];             // slicing-by-4
-  uint32_t crc_shift[kGzLevels][32];      // column j of "advance by 64 * 2^k zero bytes"
+  uint32_t crc_shift[kGzLevels][8][16];   // "advance by 64 * 2^k zero bytes" applied to nibble i holding value v
   uint32_t crc_init_full = 0;             // state reached from 0xFFFFFFFF over kGzChunk zero bytes
 };
 

@@ -40,7 +40,7 @@ struct DevDeflate {
   const uint32_t* prefix;     // member prefix words (BSIZE = 0)
   uint32_t prefix_words, prefix_bits;
   const uint32_t* crc_tab;    // [4][256]
-  const uint32_t* crc_shift;  // [kGzLevels][32]
+  const uint32_t* crc_shift;  // [kGzLevels][8][16]
   uint32_t crc_init_full, crc_init_last;
   uint32_t* next;             // [2] chunk counters of the match / encode kernels (zeroed by the host)
   uint32_t* msize;            // [n_chunks] member bytes
@@ -158,13 +158,17 @@ struct GzLane {
   uint32_t w[16];                // the lane's 64 bytes
 };
 
-// Chunk -> LDS (text frame of 32 KB aligned to the chunk's end, first-occurrence table), then the lane's greedy walk.
+// Chunk -> LDS (text frame of 32 KB aligned to the chunk's end, first-occurrence table), then the lane's matches.
 // Frame position of the lane's byte k: 64 * lane + k; data starts at kGzChunk - n.
-//   1. the gram at every EVEN data position -> table slot by ds_min (entry = position << 17 | tag): a copy whose source
-//      starts at an odd position is found one byte later, for half the inserts and a table half as crowded; a bit per
-//      position whose five bytes from the previous one on are equal (a run of >= 4 can start there)
-//   2. a bit per position whose slot holds an EARLIER position of the same tag (a candidate to copy from)
-//   3. the walk visits only positions with one of the two bits: everything else is a literal whatever the walk does
+//   1. the gram at every EVEN data position -> table slot by ds_min (entry = position << 17 | tag); a bit per position
+//      whose five bytes from the previous one on are equal (a run of >= 4 can start there), another where nine are
+//   2. at the positions 0 and 1 (mod 4): does the slot hold an earlier position with this gram's tag?  (Two residues
+//      because only even positions are in the table: a copy at an odd distance is seen from odd positions.  A copy that
+//      could start between two probed positions is found at the next one and grown backwards, so nothing is lost but
+//      the copies shorter than eleven bytes that no probe falls into with eight bytes to go.)
+//   3. the probed candidates in text order: verify the gram, extend forwards to the lane's end and backwards to the
+//      previous match; then runs (straight from the bit mask) wherever no copy went, six matches per lane in all.
+//      Positions inside a run of eight are left to the runs: their gram would be found, far away and no longer.
 // FULL: a chunk of kGzChunk bytes (all but a text's last): every lane byte is data, no predicates in 1 and 2.
 // (Grams that reach past the chunk's end take zero bytes from the padding; they sit in the chunk's last seven
 // positions, where no match of eight bytes has room, so what they leave in the table is never used.)
@@ -189,7 +193,7 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
   const uint32_t pv = lane ? ((const uint32_t*)(txt + 64u * lane))[-1] : 0u;  // the four bytes before the lane
   const uint32_t q0 = kGzChunk - n;
   const int run_from = (int)q0 - (int)(64u * lane);  // a run needs a previous DATA byte: k > run_from
-  uint32_t run_lo = 0, run_hi = 0, cand_lo = 0, cand_hi = 0;
+  uint32_t run_lo = 0, run_hi = 0, cand = 0, run8 = 0;  // cand, run8: bit 2 (k / 4) + (k & 1) for the probed k
 #pragma unroll
   for (uint32_t k = 0; k < kGzLaneBytes; k++) {
     GZ_GRAM(k, w, nx0, nx1, lo, hi)
@@ -212,74 +216,110 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
     else if (k == 0) rs &= (uint32_t)(lane != 0u);
     if (k < 32) run_lo |= rs << (k & 31u);
     else run_hi |= rs << (k & 31u);
+    if ((k & 3u) < 2u) run8 |= (rs & (uint32_t)(lo == hi)) << (2u * (k >> 2) + (k & 1u));
     if ((k & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);  // (64 independent chains: left alone the scheduler overlaps them all and spills)
   }
   __syncthreads();
   {
-    // (the words again, from LDS: held in registers across the barrier together with the 64 grams made from them the
-    // kernel would need 256 registers and spill)
-    uint32_t v[16];
-    uint32_t lane2 = lane, n0 = nx0, n1 = nx1, first2 = first;  // nothing of the first pass is worth keeping
-    asm volatile("" : "+v"(lane2), "+v"(n0), "+v"(n1), "+v"(first2));
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint4 t = ((const uint4*)(txt + 64u * lane2))[k];
-      v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
-    }
+    uint32_t lane2 = lane, first2 = first;  // nothing of the first pass is worth keeping
+    asm volatile("" : "+v"(lane2), "+v"(first2));
 #pragma unroll
     for (uint32_t k = 0; k < kGzLaneBytes; k++) {
-      GZ_GRAM(k, v, n0, n1, lo, hi)
+      if ((k & 3u) >= 2u) continue;
+      GZ_GRAM(k, w, nx0, nx1, lo, hi)
       const uint32_t q = 64u * lane2 + k;
       const uint32_t h = gz_hash(lo, hi);
       const uint32_t e = tab[h >> (32u - kGzHashBits)];
       // same tag, earlier position: the entry is smaller than what this position's own would be
       uint32_t hit = (uint32_t)(e < ((q << kGzTagBits) | (h & ((1u << kGzTagBits) - 1u)))) & (uint32_t)(((e ^ h) & ((1u << kGzTagBits) - 1u)) == 0u);
       if (!FULL) hit &= (uint32_t)(k >= first2);
-      if (k < 32) cand_lo |= hit << (k & 31u);
-      else cand_hi |= hit << (k & 31u);
-      if ((k & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
+      cand |= hit << (2u * (k >> 2) + (k & 1u));
     }
   }
-  const uint64_t runm = ((uint64_t)run_hi << 32) | run_lo, cand = ((uint64_t)cand_hi << 32) | cand_lo;
-  uint32_t nm = 0;
-  uint64_t todo = (runm | cand) & ~((first >= 64u ? ~0ull : (1ull << first) - 1ull));
-  L.starts = 0;
-  L.cover = 0;
-#pragma unroll
-  for (uint32_t j = 0; j < kGzLaneMatches; j++) L.mw[j] = 0;
+  const uint64_t runm = ((uint64_t)run_hi << 32) | run_lo;
+  uint64_t starts = 0, cover = 0, gmask = 0, gq = 0;  // gq: distance - 1 of the copies in text order, fifteen bits each
+  uint32_t gq2 = 0, nm = 0;
+  // ---- copies ----
+  {
+    uint32_t todo = cand & ~run8;
+    uint32_t lo_lim = first;  // where the previous match ended
 #pragma unroll 1
-  while (todo != 0ull && nm < kGzLaneMatches) {
-    const uint32_t k = (uint32_t)__builtin_ctzll(todo);
-    todo &= todo - 1ull;
-    const uint32_t q = 64u * lane + k, room = kGzLaneBytes - k;
-    const uint64_t own = gz_lds64(txt + q);
-    // the first eight bytes of both sources decide which one is followed: the table's candidate if its gram really is
-    // this position's (tags can collide) and the run is shorter than eight; else the run
-    const bool is_run = (runm >> k) & 1ull, is_cand = (cand >> k) & 1ull;
-    uint32_t cq = q - 1u;
-    if (is_cand) {
+    while (todo != 0u && nm < kGzLaneMatches) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(todo);
+      const uint32_t k = 4u * (bit >> 1) + (bit & 1u);
+      todo &= todo - 1u;
+      if (k < lo_lim || k + kGzGram > kGzLaneBytes) continue;
+      const uint32_t q = 64u * lane + k;
+      const uint64_t own = gz_lds64(txt + q);
       const uint32_t h = gz_hash((uint32_t)own, (uint32_t)(own >> 32));
-      cq = tab[h >> (32u - kGzHashBits)] >> kGzTagBits;
-    }
-    const uint64_t xr = is_run ? gz_lds64(txt + q - 1u) ^ own : 1ull;
-    const uint64_t xh = is_cand && cq < q ? gz_lds64(txt + cq) ^ own : 1ull;
-    const bool take_gram = xh == 0ull && xr != 0ull;
-    uint32_t src = take_gram ? cq : q - 1u;
-    uint32_t len = take_gram ? 8u : (xr ? (uint32_t)__builtin_ctzll(xr) >> 3 : 8u);
-    if (len == 8u && room > 8u) len += gz_extend(txt, src + 8u, q + 8u, room - 8u);
-    len = len < room ? len : room;
-    if (len < (take_gram ? kGzMinGramMatch : kGzMinRun)) len = 0;
-    const uint32_t d1 = q - src - 1u;
-    if (len) {
-      const uint32_t v = (len - 3u) | (d1 << 6) | 0x80000000u;
-#pragma unroll
-      for (uint32_t z = 0; z < kGzLaneMatches; z++)
-        if (z == nm) L.mw[z] = v;
+      const uint32_t cq = tab[h >> (32u - kGzHashBits)] >> kGzTagBits;
+      if (cq >= q || gz_lds64(txt + cq) != own) continue;  // (a tag can collide)
+      const uint32_t room = kGzLaneBytes - k;
+      uint32_t len = 8u + (room > 8u ? gz_extend(txt, cq + 8u, q + 8u, room - 8u) : 0u);
+      // backwards: the bytes before both, as far as they agree, down to the previous match and the start of the data
+      uint32_t back = k - lo_lim;
+      back = back < cq - q0 ? back : cq - q0;
+      if (back) {
+        const uint64_t x = gz_lds64(txt + q - 8u) ^ gz_lds64(txt + cq - 8u);  // (q >= 8 here: cq >= q0 + back, q > cq)
+        const uint32_t same = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
+        back = back < same ? back : same;
+      }
+      const uint32_t s0 = k - back;
+      len += back;
+      if (nm < 4u) gq |= (uint64_t)(q - cq - 1u) << (15u * nm);
+      else gq2 |= (q - cq - 1u) << (15u * (nm - 4u));
       nm++;
-      L.starts |= 1ull << k;
-      const uint64_t span = (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << k;
-      L.cover |= span;
-      todo &= ~span;
+      const uint64_t span = (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << s0;
+      starts |= 1ull << s0;
+      gmask |= 1ull << s0;
+      cover |= span;
+      lo_lim = s0 + len;
+      const uint32_t below = 2u * (lo_lim >> 2) + ((lo_lim & 3u) < 2u ? (lo_lim & 3u) : 2u);  // probed positions before lo_lim
+      todo &= below >= 32u ? 0u : ~((1u << below) - 1u);
+    }
+  }
+  // ---- runs, where no copy went ----
+  {
+    uint64_t r = runm & ~cover & ~(first >= 64u ? ~0ull : (1ull << first) - 1ull);
+#pragma unroll 1
+    while (r != 0ull && nm < kGzLaneMatches) {
+      const uint32_t s0 = (uint32_t)__builtin_ctzll(r);
+      const uint64_t t = ~(runm >> s0), u = cover >> s0;
+      const uint32_t ones = t ? (uint32_t)__builtin_ctzll(t) : 64u - s0;   // positions from s0 on whose next three bytes repeat
+      const uint32_t room = u ? (uint32_t)__builtin_ctzll(u) : 64u - s0;   // up to the next copy / the lane's end
+      uint32_t len = ones + 3u;
+      len = len < room ? len : room;
+      const uint64_t stretch = (ones >= 64u ? ~0ull : ((1ull << ones) - 1ull)) << s0;
+      if (len >= kGzMinRun) {
+        starts |= 1ull << s0;
+        cover |= (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << s0;
+        nm++;
+      }
+      r &= ~stretch & ~cover;
+    }
+  }
+  L.starts = starts;
+  L.cover = cover;
+  // ---- the matches in text order: length from the masks, distance from the queue (copies) or 1 (runs) ----
+  {
+    uint64_t st = starts;
+#pragma unroll
+    for (uint32_t j = 0; j < kGzLaneMatches; j++) {
+      uint32_t v = 0;
+      if (st != 0ull) {
+        const uint32_t s0 = (uint32_t)__builtin_ctzll(st);
+        st &= st - 1ull;
+        const uint64_t stop = (~cover | st) >> s0;
+        const uint32_t len = stop ? (uint32_t)__builtin_ctzll(stop) : 64u - s0;
+        uint32_t d1 = 0;
+        if ((gmask >> s0) & 1ull) {
+          d1 = (uint32_t)gq & 0x7FFFu;
+          gq = (gq >> 15) | ((uint64_t)(gq2 & 0x7FFFu) << 45);
+          gq2 >>= 15;
+        }
+        v = (len - 3u) | (d1 << 6) | 0x80000000u;
+      }
+      L.mw[j] = v;
     }
   }
 }
@@ -391,15 +431,15 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
   uint32_t* len_tok = code + 288;                  // [68]
   uint32_t* dist_code = len_tok + 68;              // [32]
   uint32_t* crc_tab = dist_code + 32;              // [4][256]
-  uint32_t* crc_shift = crc_tab + 1024;            // [kGzLevels][32]
-  uint32_t* crcs = crc_shift + kGzLevels * 32;     // [kGzThreads]
+  uint32_t* crc_shift = crc_tab + 1024;            // [kGzLevels][8][16]
+  uint32_t* crcs = crc_shift + kGzLevels * 128;    // [kGzThreads]
   uint32_t* wave_tot = crcs + kGzThreads;          // [8]
   const uint32_t lane = threadIdx.x;
   for (uint32_t i = lane; i < 288u; i += kGzThreads) code[i] = D.code[i];
   for (uint32_t i = lane; i < 68u; i += kGzThreads) len_tok[i] = D.len_tok[i];
   for (uint32_t i = lane; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
   for (uint32_t i = lane; i < 1024; i += kGzThreads) crc_tab[i] = D.crc_tab[i];
-  for (uint32_t i = lane; i < kGzLevels * 32; i += kGzThreads) crc_shift[i] = D.crc_shift[i];
+  for (uint32_t i = lane; i < kGzLevels * 128; i += kGzThreads) crc_shift[i] = D.crc_shift[i];
   __syncthreads();
   __shared__ uint32_t next_c;
   // chunks beyond a workgroup's first come from a counter (CUs do not all run at the same speed)
@@ -485,10 +525,10 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
         __syncthreads();
         if ((lane & ((2u << k) - 1u)) == 0u) {
           const uint32_t x = crcs[lane], y = crcs[lane + (1u << k)];
-          uint32_t r = 0;
-#pragma unroll 8
-          for (uint32_t j = 0; j < 32u; j++) r ^= (0u - ((x >> j) & 1u)) & crc_shift[k * 32u + j];
-          crcs[lane] = r ^ y;
+          uint32_t r = y;  // x advanced over the bytes y covers: the operator nibble by nibble
+#pragma unroll
+          for (uint32_t i = 0; i < 8u; i++) r ^= crc_shift[k * 128u + i * 16u + ((x >> (4u * i)) & 15u)];
+          crcs[lane] = r;
         }
       }
       if (lane == 0) {
@@ -542,7 +582,7 @@ void launch_gz_match(const void* d, uint32_t n_chunks, hipStream_t s) {
 void launch_gz_encode(const void* d, uint32_t n_chunks, uint32_t prefix_bits, hipStream_t s) {
   if (!n_chunks) return;
   const uint32_t sw = gz_stage_words(prefix_bits);
-  const size_t lds = ((size_t)sw + 288 + 68 + 32 + 1024 + kGzLevels * 32 + kGzThreads + 8) * 4;
+  const size_t lds = ((size_t)sw + 288 + 68 + 32 + 1024 + kGzLevels * 128 + kGzThreads + 8) * 4;
   (void)hipFuncSetAttribute((const void*)gz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const uint32_t grid = n_chunks < 512u ? n_chunks : 512u;  // two workgroups per CU fit in LDS
   hipLaunchKernelGGL(gz_encode_kernel, dim3(grid), dim3(kGzThreads), lds, s, *(const DevDeflate*)d, sw);
