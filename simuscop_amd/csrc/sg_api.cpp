@@ -177,7 +177,7 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
   SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
-  SG_ENSURE(ctx->totals, 8 * 8);
+  SG_ENSURE(ctx->totals, sg::kTotalsBytes);
   SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
   SG_HIP(hipMemcpyAsync(ctx->prefix.p, name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));
   SG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1003,7 +1003,7 @@ static int run_pass(sg_ctx* ctx) {
   if (const char* fd = getenv("SG_FDIAG")) B.diag = (uint32_t)atoi(fd);
   hipStream_t s = ctx->stream;
   const bool prof = ctx->profiling;
-  SG_HIP(hipMemsetAsync(B.totals, 0, 8 * 8, s));
+  SG_HIP(hipMemsetAsync(B.totals, 0, sg::kTotalsBytes, s));
   if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
   sg::launch_plan(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));

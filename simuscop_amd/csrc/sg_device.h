@@ -7,6 +7,10 @@
 
 namespace sg {
 
+// DevBatch::totals: 16 words of results, then (byte 128 on) the read-group counters of the two emit kernels:
+// [kernel 0 fast / 1 generic][mate][XCD partition], one 128-byte line each
+constexpr size_t kTotalsBytes = 128 + 2 * 2 * 8 * 128;
+
 // RNG stream kinds (DESIGN.md "RNG addressing"); c3 = kind | (ctx24 << 8)
 enum : uint32_t { KIND_HAP = 1, KIND_GC = 2, KIND_PLAN = 3, KIND_INDEL = 4, KIND_AUX = 5, KIND_BASE = 6 };
 
@@ -81,8 +85,8 @@ struct DevBatch {
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
   uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
+  // (from byte 128 on: the emit kernels' read-group counters, one 128-byte line each, see GroupRuns in sg_kernels.hip)
   uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full); [4] slow-queue counts;
-                                // [5],[6] group counters of the emit kernels
   uint2* slowq;                 // [2][slowq_cap] (slot, item) left to emit_slow_kernel by the fast emit kernel
   uint32_t* slowq_count;        // [2] entries appended per mate (may exceed slowq_cap: overflow)
   uint32_t slowq_cap;

@@ -729,6 +729,47 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   }
 }
 
+// Which read groups a wave does.  The groups of a mate are cut into eight contiguous partitions, one per XCD (workgroups
+// go to the XCDs round-robin by their linear id: x % 8; a grid that is not a multiple of eight gets one partition): the
+// workgroups of an XCD work through ONE eighth of the haplotype and of the text, whose lines then live in that XCD's L2.
+// Inside its partition a wave takes its first group by position and every further one from the partition's counter
+// (CUs and waves do not run at one speed; with a static stride the grid drained 18 % late), then from the other
+// partitions' counters.  One counter per partition,
+// each in a cache line of its own, because one address serves ~85 M atomics per second: a single counter per mate was
+// the ceiling of the whole kernel for 75-base reads (410 k groups per C2 pass = 4.8 ms whatever the groups cost).
+struct GroupRuns {
+  uint32_t* counters;        // this kernel's and mate's eight counters, 32 words apart
+  uint32_t ngroups, P, part, tried, waves_per_part;
+  uint32_t g;                // the wave's current group (uniform); valid while more()
+  bool ok;
+  __device__ __forceinline__ uint32_t lo(uint32_t p) const { return (uint32_t)((uint64_t)ngroups * p / P); }
+  __device__ __forceinline__ GroupRuns(uint64_t* totals, uint32_t kernel, uint32_t mate, uint32_t n, uint32_t wv, uint32_t waves_per_wg) {
+    ngroups = n;
+    P = (gridDim.x & 7u) == 0u ? 8u : 1u;
+    part = P == 8u ? blockIdx.x & 7u : 0u;
+    tried = 0;
+    waves_per_part = (gridDim.x / P) * waves_per_wg;
+    counters = (uint32_t*)((uint8_t*)totals + 128) + (kernel * 2u + mate) * 8u * 32u;
+    g = lo(part) + (P == 8u ? blockIdx.x >> 3 : blockIdx.x) * waves_per_wg + wv;
+    ok = g < lo(part + 1u);
+  }
+  __device__ __forceinline__ bool more() const { return ok; }
+  // the next group: from the own partition's counter; when that is exhausted, from the next partition's (the XCDs do not
+  // finish together either), until all eight have been tried
+  __device__ __forceinline__ void next(uint32_t lane) {
+    for (;;) {
+      uint32_t nx = 0;
+      if (lane == 0u) nx = atomicAdd(counters + part * 32u, 1u);
+      nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+      const uint32_t first_dyn = lo(part) + waves_per_part, end = lo(part + 1u);
+      g = first_dyn + nx;
+      if (first_dyn < end && nx < end - first_dyn) { ok = true; return; }
+      part = part + 1u == P ? 0u : part + 1u;
+      if (++tried >= P) { ok = false; return; }
+    }
+  }
+};
+
 template <int KT, bool SUB_LDS>
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBatch B, uint32_t sub_rows, uint32_t TI, uint32_t RPI) {
   extern __shared__ uint4 smem[];
@@ -749,10 +790,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
   const uint32_t sub = lane / TI, c_lane = lane - sub * TI;  // fixed lane -> (read in iteration, item)
   const bool lane_ok = sub < RPI;
 
-  // first group by position, further ones from a per-mate counter (its own: this kernel also re-emits a
-  // batch after emit_fast_kernel has run, see sg_result)
-  uint32_t* next_group = (uint32_t*)(B.totals + 6) + m;
-  for (uint32_t g = blockIdx.x * EMIT_WAVES + wv; g < ngroups;) {
+  // groups from a counter of its own: this kernel also re-emits a batch after emit_fast_kernel has run (sg_result)
+  GroupRuns runs(B.totals, 1u, m, ngroups, wv, EMIT_WAVES);
+  for (; runs.more(); runs.next(lane)) {
+    const uint32_t g = runs.g;
     // ================= phase 0: lane = read: its 32-byte row (coalesced) into LDS =================
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
@@ -804,9 +845,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
     }
 
     wave_lds_sync();  // the next group's phase 0 rewrites the metadata rows
-    uint32_t nx = 0;
-    if (lane == 0u) nx = atomicAdd(next_group, 1u);
-    g = gridDim.x * EMIT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
   }
 }
 
@@ -1095,15 +1133,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   // ones).  inv_TI = ceil-reciprocal of TI.
   const uint32_t G = 63u;
   const uint32_t ngroups = (B.n_slots + G - 1u) / G;
-  // XCD-aware order: workgroups go to the 8 XCDs round-robin by their linear id, so the 16 workgroups of
-  // one XCD (x % 8 equal; both mates) take 16 CONSECUTIVE runs of read groups each round -- neighbouring
-  // reads overlap on the haplotype (30x coverage), and their lines are then fetched into one L2 instead of
-  // eight.
-  const uint32_t bx = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  // first group by position, further groups from a per-mate counter: waves that drew cheap groups (few
-  // event reads) take more of them, so the grid drains evenly
-  uint32_t* next_group = (uint32_t*)(B.totals + 5) + m;
-  for (uint32_t g = bx * EMIT_WAVES + wv; g < ngroups;) {
+  GroupRuns runs(B.totals, 0u, m, ngroups, wv, EMIT_WAVES);
+  for (; runs.more(); runs.next(lane)) {
+    const uint32_t g = runs.g;
     const uint32_t t = g * G + lane;
     uint32_t items = 0;
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
@@ -1391,9 +1423,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
     }
     wave_lds_sync();
-    uint32_t nx = 0;
-    if (lane == 0u) nx = atomicAdd(next_group, 1u);
-    g = gridDim.x * EMIT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
   }
 }
 
