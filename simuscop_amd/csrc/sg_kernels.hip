@@ -170,23 +170,56 @@ __global__ __launch_bounds__(64) void namebase_kernel(DevBatch B) {
   if (lane == 0) atomicAdd((unsigned long long*)&B.totals[2], (unsigned long long)carry);
 }
 
+// Orders one wave's LDS writes before its later LDS reads by other lanes (wave-private staging rows).  Wavefront scope:
+// the LDS executes one wave's operations in issue order, so only the compiler has to be held back -- a workgroup-scope
+// fence would also wait for every global store the wave has in flight (s_waitcnt vmcnt(0)), several times per read group.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------
 // indel pass: one lane per read
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
+  // The reads' 64-byte rows leave through LDS: written by their lanes (16 bytes and single words at a stride of 64
+  // bytes: straight to memory every store instruction touched 64 cache lines), stored by the wave as 4 KB in one piece.
+  __shared__ uint4 row_lds[256 * 4];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
-  if (t >= B.n_slots) return;
-  const size_t idx = (size_t)m * B.n_slots + t;
-  const PairRec rec = B.pairs[t];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint4* const wave_rows = row_lds + (threadIdx.x & ~63u) * 4u;
+  uint4* const my_row = wave_rows + lane * 4u;
+  const uint32_t t_wave = t - lane;  // the wave's first slot
+  auto store_rows = [&]() {
+    wave_lds_sync();
+    uint4* dst = B.meta + ((size_t)m * B.n_slots + t_wave) * 4;
+    const uint32_t n_rows = B.n_slots - t_wave;  // rows of the wave that exist (>= 1: lane 0 is inside the batch)
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+      const uint32_t q = i * 64u + lane;  // 16-byte piece of the wave's block: row q / 4
+      if ((q >> 2) < n_rows) dst[q] = wave_rows[q];
+    }
+  };
+  const bool in_batch = t < B.n_slots;
+  const size_t idx = (size_t)m * B.n_slots + (in_batch ? t : 0u);
+  PairRec rec = {};
+  if (in_batch) rec = B.pairs[t];
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
-  if (!flen) {
-    B.rlen[idx] = 0; B.reclen[idx] = 0;
-    B.meta[idx * 4] = make_uint4(0, 0, 0, 0);
-    B.meta[idx * 4 + 1] = make_uint4(0, 0, 0, 0);
+  if (__ballot(flen != 0u) == 0ull) {  // nothing planned in the whole wave
+    if (in_batch) { B.rlen[idx] = 0; B.reclen[idx] = 0; }
+    my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
+    if (t_wave < B.n_slots) store_rows();
     return;
   }
-  const int L = P.L;
+  if (!flen) {
+    if (in_batch) { B.rlen[idx] = 0; B.reclen[idx] = 0; }
+    my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
+  }
+  // (lanes without a fragment stay in the kernel for the wave-wide steps below, doing nothing in between)
+  const bool live = flen != 0u;
+  const int L = live ? P.L : 0;
   int j = 0, dl = 0;
   uint32_t nev = 0, first_ev = 0;
   uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
@@ -284,62 +317,65 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
       if (min_head(x) <= hB) walk_chunk(c, x);
     }
   }
-  if (L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
-  if (nev > SG_MAX_EVENTS) { atomicOr((unsigned long long*)&B.totals[3], 1ull); nev = 0; dl = 0; }
-  const uint32_t np = (uint32_t)(L + dl);
-  B.rlen[idx] = np | (nev << 16);
-  const sg_window win = B.windows[rec.win];
-  const uint32_t pos = win.spos + rec.relpos;
-  const uint32_t namepos = pos % B.seg_size[win.seg];
-  const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-  const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
-  B.reclen[idx] = hdr + 2u * np + 4u;
-  // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
-  // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
-  // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
-  const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
-  const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
-  // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
-  // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
-  // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
-  uint32_t touches_bad = 0;
-  {
-    const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
-    for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
+  if (live) {
+    if (L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
+    if (nev > SG_MAX_EVENTS) { atomicOr((unsigned long long*)&B.totals[3], 1ull); nev = 0; dl = 0; }
+    const uint32_t np = (uint32_t)(L + dl);
+    B.rlen[idx] = np | (nev << 16);
+    const sg_window win = B.windows[rec.win];
+    const uint32_t pos = win.spos + rec.relpos;
+    const uint32_t namepos = pos % B.seg_size[win.seg];
+    const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
+    const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
+    B.reclen[idx] = hdr + 2u * np + 4u;
+    // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
+    // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
+    // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
+    const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
+    const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
+    // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
+    // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
+    // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
+    uint32_t touches_bad = 0;
+    {
+      const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
+      for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
+    }
+    my_row[0] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
+    // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
+    // (sg_load_profile rejects profiles that could violate the bound)
+    // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
+    my_row[1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
+                                     nev == 1u ? first_ev : 0u);
+    if (hdr <= 32u) {
+      uint32_t* hp = (uint32_t*)(my_row + 2);
+      uint32_t w = 0, nb = 0;
+      auto push = [&](uint32_t b) {
+        w |= b << (nb * 8u);
+        if (++nb == 4u) { *hp++ = w; w = 0; nb = 0; }
+      };
+      auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
+        const uint32_t nd = ndigits(v);
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+        for (uint32_t k = 0; k < nd; k++) {
+          const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
+          if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
+          v = qd;
+        }
+        for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
+        for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
+      };
+      for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);  // hdr <= 32 implies prefix <= 16
+      push_dec(namepos);
+      push('#');
+      push_dec(fragcount);
+      if (B.paired) { push('/'); push('1' + m); }
+      push('\n');
+      if (nb) *hp = w;
+    }
   }
-  B.meta[idx * 4] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
-  // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
-  // (sg_load_profile rejects profiles that could violate the bound)
-  // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
-  B.meta[idx * 4 + 1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
-                                   nev == 1u ? first_ev : 0u);
-  if (hdr <= 32u) {
-    uint32_t* hp = (uint32_t*)(B.meta + idx * 4 + 2);
-    uint32_t w = 0, nb = 0;
-    auto push = [&](uint32_t b) {
-      w |= b << (nb * 8u);
-      if (++nb == 4u) { *hp++ = w; w = 0; nb = 0; }
-    };
-    auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
-      const uint32_t nd = ndigits(v);
-      uint64_t lo = 0;
-      uint32_t hi = 0;
-      for (uint32_t k = 0; k < nd; k++) {
-        const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
-        if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
-        v = qd;
-      }
-      for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
-      for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
-    };
-    for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);  // hdr <= 32 implies prefix <= 16
-    push_dec(namepos);
-    push('#');
-    push_dec(fragcount);
-    if (B.paired) { push('/'); push('1' + m); }
-    push('\n');
-    if (nb) *hp = w;
-  }
+  store_rows();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,15 +541,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 #define EMIT_THREADS 1024
 #define EMIT_WAVES (EMIT_THREADS / 64)
 #define META_ROW 32  // bytes of LDS metadata per read
-
-// Orders one wave's LDS writes before its later LDS reads by other lanes (wave-private staging rows).  Wavefront scope:
-// the LDS executes one wave's operations in issue order, so only the compiler has to be held back -- a workgroup-scope
-// fence would also wait for every global store the wave has in flight (s_waitcnt vmcnt(0)), several times per read group.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Source codes of a read that carries sequencing-indel events (rare path, kept OUT OF LINE and
 // un-unrolled: inlined it pushed the kernel past the 64 KB instruction cache and cost 2x).
