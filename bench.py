@@ -115,6 +115,8 @@ def pmc_evidence():
            "traffic": (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0}
     if "SQ_INSTS_VALU" in v:
         out["valu"] = v["SQ_INSTS_VALU"]["mean_per_dispatch"]
+    if "GRBM_GUI_ACTIVE" in v:   # summed over the 8 XCDs: / 8 = the kernel's duration in shader clocks
+        out["kernel_cycles"] = v["GRBM_GUI_ACTIVE"]["mean_per_dispatch"] / 8.0
     return out
 
 
@@ -304,8 +306,11 @@ def main():
             # depend on the run) x the microbenchmarked cycles per instruction, over 1024 SIMDs x this run's kernel time
             compute_side = {"bound": "integer VALU issue", "valu_wave_instructions_per_launch": pmc["valu"],
                             "cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION, "cost_model": "tools/valu_microbench.hip",
-                            "valu_issue_occupancy": pmc["valu"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * emit_ms * 1e-3 * 2.4e9),
-                            "clock_GHz_assumed": 2.4, "source": pmc["source"]}
+                            "valu_issue_occupancy_live": pmc["valu"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * emit_ms * 1e-3 * 2.35e9),
+                            "clock_GHz_assumed": 2.35, "source": pmc["source"]}
+            if "kernel_cycles" in pmc:  # both numbers from the same counter passes: no clock assumed
+                compute_side["kernel_cycles_counter_pass"] = pmc["kernel_cycles"]
+                compute_side["valu_issue_occupancy"] = pmc["valu"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * pmc["kernel_cycles"])
         out = {
             "metric": "simulated paired reads/sec (whole node) at 30x WGS PE150",
             "value": total_pairs / dt_max,
