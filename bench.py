@@ -124,7 +124,7 @@ def host_pinned_rate(sess, steps, gzip):
     """SURVEY 8(d) metric: pairs whose FASTQ text is complete in pinned host memory.  Each pass's text leaves the
     context as a detached output set and drains over PCIe (64 MB pinned buffers, two per mate) on a worker thread
     while the next pass is sampled (and compressed) on the main stream."""
-    CH = 64 << 20
+    CH = int(os.environ.get("BENCH_DRAIN_MB", "64")) << 20
     bufs = [sess.host_alloc(CH) for _ in range(4)]
     moved = [0]
 
