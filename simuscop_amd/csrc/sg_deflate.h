@@ -27,7 +27,7 @@ constexpr int kGzDistSyms = 30;          // distance alphabet
 constexpr uint32_t kGzGram = 8;          // bytes hashed per position
 constexpr uint32_t kGzHashBits = 13;     // first-occurrence table: 8192 entries in LDS
 constexpr uint32_t kGzMinGramMatch = 8;  // shortest match taken from the table (and only where the run is shorter than that)
-constexpr uint32_t kGzMinRun = 4;        // shortest match taken at distance 1
+constexpr uint32_t kGzMinRun = 5;        // shortest match taken at distance 1
 constexpr uint32_t kGzMaxMatch = 64;     // a match never leaves its lane's 64 bytes (RFC limit: 258)
 constexpr uint32_t kGzLaneMatches = 6;   // matches per lane; what follows them in the lane is literals
 constexpr uint32_t kGzSamples = 512;     // members sampled for the token histogram (16 MB of text), spread evenly

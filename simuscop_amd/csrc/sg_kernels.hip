@@ -348,31 +348,29 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     my_row[1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
                                      nev == 1u ? first_ev : 0u);
     if (hdr <= 32u) {
-      uint32_t* hp = (uint32_t*)(my_row + 2);
-      uint32_t w = 0, nb = 0;
-      auto push = [&](uint32_t b) {
-        w |= b << (nb * 8u);
-        if (++nb == 4u) { *hp++ = w; w = 0; nb = 0; }
-      };
-      auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
+      // text straight into the row's last 32 bytes (LDS): the prefix as words, then single characters -- the digits of a
+      // number from its last one backwards
+      uint8_t* hb = (uint8_t*)(my_row + 2);
+      if (B.prefix_len <= 16u) {
+        my_row[2] = make_uint4(B.prefix_w[0], B.prefix_w[1], B.prefix_w[2], B.prefix_w[3]);
+      } else {
+        for (uint32_t i = 0; i < B.prefix_len; i++) hb[i] = B.prefix[i];  // (B.prefix_w holds 16 bytes)
+      }
+      uint32_t o = B.prefix_len;
+      auto put_dec = [&](uint32_t v) {
         const uint32_t nd = ndigits(v);
-        uint64_t lo = 0;
-        uint32_t hi = 0;
-        for (uint32_t k = 0; k < nd; k++) {
-          const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
-          if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
+        for (uint32_t k = nd; k-- > 0u;) {
+          const uint32_t qd = v / 10u;
+          hb[o + k] = (uint8_t)('0' + (v - qd * 10u));
           v = qd;
         }
-        for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
-        for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
+        o += nd;
       };
-      for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);  // hdr <= 32 implies prefix <= 16
-      push_dec(namepos);
-      push('#');
-      push_dec(fragcount);
-      if (B.paired) { push('/'); push('1' + m); }
-      push('\n');
-      if (nb) *hp = w;
+      put_dec(namepos);
+      hb[o++] = '#';
+      put_dec(fragcount);
+      if (B.paired) { hb[o++] = '/'; hb[o++] = (uint8_t)('1' + m); }
+      hb[o] = '\n';
     }
   }
   store_rows();

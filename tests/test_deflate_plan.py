@@ -24,7 +24,7 @@ def _dsym(dist):
     return max(i for i in range(30) if DBASE[i] <= dist)
 
 
-def tokens(data, lane=64, min_gram=8, min_run=4, per_lane=6):
+def tokens(data, lane=64, min_gram=8, min_run=5, per_lane=6):
     """sg_deflate.hip's walk over one member (<= 32 KB): per lane of 64 bytes (aligned to the END of the chunk), greedy;
     candidates are the first occurrence -- at an even position of the chunk's 32 KB frame -- of the position's 8-byte gram,
     taken where the run at the position is shorter than eight, and the previous byte; at most six matches per lane.
