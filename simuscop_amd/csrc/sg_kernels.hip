@@ -1077,14 +1077,22 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   // vmcnt(1), a full store round trip exposed in every step).  The read's last, partial item (np % 8 bases) is parked
   // in the read's own LDS row: the per-read pass after the step loop merges it with the record separators, so the
   // byte-granular stores run once per read group rather than in every step.
+  // A last item of exactly seven bases (np % 8 == 7: every read without an indel of the 151-base profile) is a whole
+  // item too -- its eighth byte is the line break that follows the bases / the qualities -- so it leaves with the steps,
+  // next to its neighbours, instead of coming back to half-written lines from the per-read pass.
   {
-    const bool whole = i0 + 8u <= np;
+    const bool last7 = i0 + 7u == np;
+    const bool whole = i0 + 8u <= np || last7;
     const bool st = go && whole && !(B.diag & 1u);
     const uint32_t so_ = st ? m0.z + hdr + i0 : 0xFFFFFFFFu;
     const uint32_t qo_ = st ? so_ + np + 3u : 0xFFFFFFFFu;
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, so_, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, qo_, 0, 0);
-    if (active && !whole) {
+    const uint32_t s1 = last7 ? (sw[1] & 0x00FFFFFFu) | 0x0A000000u : sw[1];
+    const uint32_t q1 = last7 ? (qw[1] & 0x00FFFFFFu) | 0x0A000000u : qw[1];
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], s1}, out_rsrc, so_, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], q1}, out_rsrc, qo_, 0, 0);
+    // ... and the "+\n" between the two line breaks, by the same lane (a third store on every path, dropped elsewhere)
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0x0A2Bu, out_rsrc, st && last7 ? so_ + 8u : 0xFFFFFFFFu, 0, 0);
+    if (active && i0 + 8u > np && !(last7 && !slow)) {
       // parked over the fields no lane needs once the last item has been sampled (fragment offset, 2^32/n',
       // event): base characters are never 0xFF
       tail_row[0].x = slow ? 0xFFFFFFFFu : sw[0];
@@ -1259,7 +1267,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         if (on) {
           const uint4 r0 = meta_rows[r * 2], r1 = meta_rows[r * 2 + 1];
           const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22, i = 8u * c + h;
-          if (8u * c + 8u <= np) {
+          if (8u * c + 8u <= np + (uint32_t)((np & 7u) == 7u)) {  // (a last item of seven bases was stored like a whole one)
             uint8_t* rec = gout + r0.z + hl + i;
             rec[0] = (uint8_t)ch;
             rec[np + 3u] = (uint8_t)sym;
@@ -1389,11 +1397,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     };
     if (nmain) {
       Stage cur = fetch_step(0);
-      // two (dropped) stores: the loop is then entered with the same three vector-memory operations behind the first
-      // prefetch as every later iteration has behind its own (two item stores + the next prefetch), and the wait for a
-      // prefetched window stays vmcnt(3) instead of falling back to the entry path's vmcnt(1)
+      // three (dropped) stores: the loop is then entered with the same vector-memory operations behind the first
+      // prefetch as every later iteration has behind its own (three item stores + the next prefetch), and the wait for a
+      // prefetched window stays a counted one instead of falling back to the entry path's vmcnt(1)
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0u, out_rsrc, 0xFFFFFFE0u, 0, 0);
       for (uint32_t step = 0; step < nmain; step++) {
         if (nslow > SLOW_CAP - 64u) flush_slow();
         // (the last step fetches itself again: an unconditional fetch keeps the loaded registers free of copies until
@@ -1436,15 +1445,19 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           else store_var(q, ((uint64_t)part.y << 32) | part.x, ((uint64_t)part.w << 32) | part.z, rem);
         }
         const uint4 tr = make_uint4(r0.x, r0.y, r1.z, r1.w);  // the parked last item (fast_item)
-        const uint32_t d = (tr.x != 0xFFFFFFFFu) ? (np & 7u) : 0u;  // bases (and qualities) of the partial item
-        const uint64_t S = ((uint64_t)tr.y << 32) | tr.x, Q = ((uint64_t)tr.w << 32) | tr.z;
-        const uint64_t keep = (1ull << (8u * d)) - 1ull;
-        uint8_t* so = rec + hl + (np - d);
-        // d bases + "\n+\n" (3..10 bytes), d qualities + '\n' (1..8 bytes)
-        const uint64_t s_lo = (S & keep) | (0x0A2B0Aull << (8u * d));
-        const uint64_t s_hi = d > 5u ? (0x0A2B0Aull >> (8u * (8u - d))) : 0ull;
-        store_var(so, s_lo, s_hi, d + 3u);
-        store_var(so + np + 3u, (Q & keep) | (0x0Aull << (8u * d)), 0ull, d + 1u);
+        if ((np & 7u) == 7u && tr.x != 0xFFFFFFFFu) {
+          // the last item went out with the steps, line breaks and the "+" line included
+        } else {
+          const uint32_t d = (tr.x != 0xFFFFFFFFu) ? (np & 7u) : 0u;  // bases (and qualities) of the partial item
+          const uint64_t S = ((uint64_t)tr.y << 32) | tr.x, Q = ((uint64_t)tr.w << 32) | tr.z;
+          const uint64_t keep = (1ull << (8u * d)) - 1ull;
+          uint8_t* so = rec + hl + (np - d);
+          // d bases + "\n+\n" (3..10 bytes), d qualities + '\n' (1..8 bytes)
+          const uint64_t s_lo = (S & keep) | (0x0A2B0Aull << (8u * d));
+          const uint64_t s_hi = d > 5u ? (0x0A2B0Aull >> (8u * (8u - d))) : 0ull;
+          store_var(so, s_lo, s_hi, d + 3u);
+          store_var(so + np + 3u, (Q & keep) | (0x0Aull << (8u * d)), 0ull, d + 1u);
+        }
       }
     }
     wave_lds_sync();
