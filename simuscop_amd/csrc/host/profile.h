@@ -26,7 +26,6 @@ struct Profile {
   int max_insert_size() const { return isize_cdf.empty() ? insert_size : isize_min + (int)isize_cdf.size() - 1; }
   // view for sg_load_profile (pointers stay valid while *this lives)
   sg_profile_cdf view() const;
-  // Profile::getGCFactor (Profile.cpp:1507-1517) with an addressed Philox Box-Muller draw
   // The standard normal behind the GC factor (Profile::getGCFactor, Profile.cpp:1507-1517) as a quantile table the
   // device interpolates (sg_window_weights): 2^14 cells of equal probability, knots Phi^-1(k / 2^14) by bisection on
   // erfc (DESIGN.md section 4 "GC factor").

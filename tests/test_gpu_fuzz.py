@@ -90,7 +90,7 @@ def test_random_configuration(case_seed, oracle_lib, tmp_path):
         if rng.random() < 0.3:
             env["SIMU_PIECE_SLOTS"] = str(rng.choice([1, 700, 5000]))
         if rng.random() < 0.2:
-            env["SG_EMIT_MAP"] = "fixed"
+            env["SIMU_HOST_PLAN"] = "1"   # GC windows, weights and read counts on the host instead of the device planner
         if rng.random() < 0.2:
             env["SG_SLOWQ_CAP"] = str(rng.choice([1, 64, 4096]))
     r = subprocess.run([SIMU, cfg, "--seed", str(seed), "--out", gdir, "--quiet", *extra], capture_output=True, text=True, timeout=120, env=env)
