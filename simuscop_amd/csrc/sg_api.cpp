@@ -23,7 +23,8 @@ void launch_plan(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_namebase(const DevBatch& B, hipStream_t s);
 void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
-void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s);
+void launch_scan(const DevBatch& B, hipStream_t s);
+uint32_t record_seg_shift(uint32_t n_slots);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main);
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
@@ -175,10 +176,10 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   SG_ENSURE(ctx->rlen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
   SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
-  SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 8);
+  SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
   SG_ENSURE(ctx->totals, sg::kTotalsBytes);
-  SG_ENSURE(ctx->bsum, ((size_t)nm * sg::scan_blocks(n_slots) + 1) * 8);
+  SG_ENSURE(ctx->bsum, ((size_t)nm * ((n_slots + 255) / 256) + 1) * 8);
   SG_HIP(hipMemcpyAsync(ctx->prefix.p, name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));
   SG_HIP(hipStreamSynchronize(ctx->stream));
 
@@ -203,7 +204,9 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   B.rlen = ctx->rlen.as<uint32_t>();
   B.events = ctx->events.as<uint32_t>();
   B.reclen = ctx->reclen.as<uint32_t>();
-  B.recoff = ctx->recoff.as<uint64_t>();
+  B.recloc = ctx->recoff.as<uint32_t>();
+  B.blkbase = ctx->bsum.as<uint64_t>();
+  B.seg_shift = sg::record_seg_shift((uint32_t)n_slots);
   B.meta = ctx->meta.as<uint4>();
   B.totals = ctx->totals.as<uint64_t>();
   B.slowq_count = (uint32_t*)(B.totals + 4);
@@ -1011,7 +1014,7 @@ static int run_pass(sg_ctx* ctx) {
   if (prof) SG_HIP(hipEventRecord(ctx->evs[2], s));
   sg::launch_indel(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[3], s));
-  sg::launch_scan(B, ctx->bsum.as<uint64_t>(), s);
+  sg::launch_scan(B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[4], s));
   SG_HIP(hipGetLastError());
   // The FASTQ size is only known now.  Reading two u64 back costs one stream sync per batch

@@ -9,7 +9,9 @@ namespace sg {
 
 // DevBatch::totals: 16 words of results, then (byte 128 on) the read-group counters of the two emit kernels:
 // [kernel 0 fast / 1 generic][mate][XCD partition], one 128-byte line each
-constexpr size_t kTotalsBytes = 128 + 2 * 2 * 8 * 128;
+// then [2][16] u64 segment bases of the record offsets (block_base_kernel) and its two arrival counters
+constexpr size_t kTotalsSegBase = 128 + 2 * 2 * 8 * 128;
+constexpr size_t kTotalsBytes = kTotalsSegBase + 2 * 16 * 8 + 64;
 
 // RNG stream kinds (DESIGN.md "RNG addressing"); c3 = kind | (ctx24 << 8)
 enum : uint32_t { KIND_HAP = 1, KIND_GC = 2, KIND_PLAN = 3, KIND_INDEL = 4, KIND_AUX = 5, KIND_BASE = 6 };
@@ -83,7 +85,10 @@ struct DevBatch {
   uint32_t* rlen;               // [2][n_slots]  n' | nev<<16
   uint32_t* events;             // [2][n_slots][SG_MAX_EVENTS]
   uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
-  uint64_t* recoff;             // [2][n_slots] exclusive scan of reclen
+  uint32_t* recloc;             // [2][n_slots] exclusive prefix of reclen inside the read's block of 256 (indel_kernel)
+  uint64_t* blkbase;            // [2][ceil(n_slots / 256)] offset of a block's first record inside its segment of 2^seg_shift blocks
+                                // (sums by indel_kernel, scanned in place by block_base_kernel; the segments' own bases: totals + kTotalsSegBase)
+  uint32_t seg_shift;
   uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
   // (from byte 128 on: the emit kernels' read-group counters, one 128-byte line each, see GroupRuns in sg_kernels.hip)
   uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full); [4] slow-queue counts;

@@ -179,6 +179,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Byte offset of read t's record in its mate's text: base of its segment of 2^seg_shift blocks + base of its block of
+// 256 reads inside the segment + prefix inside the block (indel_kernel, block_base_kernel)
+__device__ __forceinline__ uint64_t rec_offset(const DevBatch& B, uint32_t m, uint32_t t) {
+  const uint32_t blk = t >> 8;
+  const uint64_t* segbase = (const uint64_t*)((const uint8_t*)B.totals + kTotalsSegBase);
+  return segbase[m * 16u + (blk >> B.seg_shift)] + B.blkbase[(size_t)m * ((B.n_slots + 255u) >> 8) + blk] +
+         B.recloc[(size_t)m * B.n_slots + t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // indel pass: one lane per read
 // ------------------------------------------------------------------------------------------------
@@ -207,10 +216,34 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   PairRec rec = {};
   if (in_batch) rec = B.pairs[t];
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
+  uint32_t rl = 0;  // the read's record length (0: nothing planned)
+  // Record offsets: exclusive prefix of the record lengths inside the block of 256 reads, here; the blocks' bases by
+  // one small kernel afterwards (scan_sums_kernel).  offset = base[block] + prefix (rec_offset()).
+  __shared__ uint32_t wave_len[4];
+  auto block_prefix = [&]() {
+    uint32_t incl = rl;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) wave_len[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+      const uint32_t w = wave_len[i];
+      if (i < (threadIdx.x >> 6)) base += w;
+      all += w;
+    }
+    if (in_batch) B.recloc[idx] = base + incl - rl;
+    if (threadIdx.x == 0) B.blkbase[(size_t)m * gridDim.x + blockIdx.x] = all;
+  };
   if (__ballot(flen != 0u) == 0ull) {  // nothing planned in the whole wave
     if (in_batch) { B.rlen[idx] = 0; B.reclen[idx] = 0; }
     my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
     if (t_wave < B.n_slots) store_rows();
+    block_prefix();
     return;
   }
   if (!flen) {
@@ -327,7 +360,8 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     const uint32_t namepos = pos % B.seg_size[win.seg];
     const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
     const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
-    B.reclen[idx] = hdr + 2u * np + 4u;
+    rl = hdr + 2u * np + 4u;
+    B.reclen[idx] = rl;
     // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
     // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
     // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
@@ -374,6 +408,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     }
   }
   store_rows();
+  block_prefix();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,7 +425,7 @@ __global__ __launch_bounds__(256) void header_kernel(DevBatch B, uint32_t only_l
   if (!(m1.x & 0x7FFFFFFFu)) return;
   if (only_long && (m1.y >> 22) <= 32u) return;  // written by the emit kernel from the row
   const uint4 m0 = B.meta[idx * 4];
-  const uint64_t ooff = B.recoff[idx];
+  const uint64_t ooff = rec_offset(B, m, t);
   if (ooff + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
   const uint32_t namepos = m0.z, fragcount = m0.w;
   if (!(B.diag & 4u)) {
@@ -472,29 +507,79 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const uint32_t*
 
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint64_t* __restrict__ bsum, uint32_t nblk,
                                                         uint64_t* __restrict__ totals) {
-  // one block per mate; sequential chunks of 1024 with a Hillis-Steele scan in LDS
+  // one block per row (mate): thread i owns a run of ceil(nblk / 1024) consecutive sums -- adds them up, the 1024 run
+  // totals are scanned in LDS (one Hillis-Steele pass), then every thread writes the exclusive prefixes of its run
   __shared__ uint64_t buf[1024];
   const uint32_t m = blockIdx.x;
   uint64_t* b = bsum + (size_t)m * nblk;
-  uint64_t carry = 0;
-  for (uint32_t base = 0; base < nblk; base += 1024) {
-    uint32_t i = base + threadIdx.x;
-    uint64_t v = i < nblk ? b[i] : 0;
-    buf[threadIdx.x] = v;
+  const uint32_t run = (nblk + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * run, hi = min(lo + run, nblk);
+  uint64_t mine = 0;
+  for (uint32_t i = lo; i < hi; i++) mine += b[i];
+  buf[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint64_t t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-      uint64_t t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
-      __syncthreads();
-      buf[threadIdx.x] += t;
-      __syncthreads();
-    }
-    uint64_t incl = buf[threadIdx.x];
-    if (i < nblk) b[i] = carry + incl - v;
-    uint64_t chunk_total = buf[1023];
+    buf[threadIdx.x] += t;
     __syncthreads();
-    carry += chunk_total;
   }
-  if (threadIdx.x == 0) totals[m] = carry;
+  uint64_t carry = buf[threadIdx.x] - mine;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint64_t v = b[i];
+    b[i] = carry;
+    carry += v;
+  }
+  if (threadIdx.x == 1023u) totals[m] = buf[1023];
+}
+
+// Record offsets, middle level: the block sums indel_kernel left in blkbase, cut into <= 16 segments of 2^seg_shift
+// blocks; workgroup j scans segment j in place (thread i owns a run of consecutive sums), the workgroup that arrives
+// last turns the 16 segment totals into segment bases and the mate's text size (totals[m]).  One launch, 16 CUs per
+// mate busy instead of one.
+__global__ __launch_bounds__(1024) void block_base_kernel(DevBatch B) {
+  __shared__ uint64_t buf[1024];
+  __shared__ uint32_t ticket;
+  const uint32_t m = blockIdx.y, j = blockIdx.x;
+  const uint32_t nblk = (B.n_slots + 255u) >> 8;
+  uint64_t* b = B.blkbase + (size_t)m * nblk;
+  uint64_t* segbase = (uint64_t*)((uint8_t*)B.totals + kTotalsSegBase) + m * 16u;
+  uint32_t* arrived = (uint32_t*)((uint8_t*)B.totals + kTotalsSegBase + 2 * 16 * 8) + m;
+  const uint32_t s0 = min(j << B.seg_shift, nblk), s1 = min((j + 1u) << B.seg_shift, nblk);
+  const uint32_t run = ((s1 - s0) + 1023u) / 1024u;
+  const uint32_t lo = min(s0 + threadIdx.x * run, s1), hi = min(lo + run, s1);
+  uint64_t mine = 0;
+  for (uint32_t i = lo; i < hi; i++) mine += b[i];
+  buf[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint64_t t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+    __syncthreads();
+    buf[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint64_t carry = buf[threadIdx.x] - mine;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint64_t v = b[i];
+    b[i] = carry;
+    carry += v;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&segbase[j], buf[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    ticket = atomicAdd(arrived, 1u);
+  }
+  __syncthreads();
+  if (ticket + 1u == gridDim.x && threadIdx.x == 0) {  // every segment total is in: bases, text size
+    __threadfence();
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < gridDim.x; i++) {
+      const uint64_t v = __hip_atomic_load(&segbase[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&segbase[i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc += v;
+    }
+    B.totals[m] = acc;
+  }
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t n,
@@ -827,7 +912,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
       const size_t idx = (size_t)m * B.n_slots + t;
       my0 = B.meta[idx * 4];
       my1 = B.meta[idx * 4 + 1];
-      const uint64_t ooff = B.recoff[idx];
+      const uint64_t ooff = rec_offset(B, m, t);
       my0.z = (uint32_t)ooff;
       my0.w = (uint32_t)(ooff >> 32);
       if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 10u) / 8u;  // ceil((np + 3) / 8): bases + "\n+\n"
@@ -1177,7 +1262,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const size_t idx = (size_t)m * B.n_slots + t;
       my0 = B.meta[idx * 4];
       my1 = B.meta[idx * 4 + 1];
-      ooff = B.recoff[idx];
+      ooff = rec_offset(B, m, t);
       if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
     }
     // The group's text is one contiguous range starting at its first record: a buffer descriptor on that address, the
@@ -1487,7 +1572,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, D
     const size_t idx = (size_t)m * B.n_slots + e.x;
     uint4 m0 = B.meta[idx * 4];
     const uint4 m1 = B.meta[idx * 4 + 1];
-    const uint64_t ooff = B.recoff[idx];
+    const uint64_t ooff = rec_offset(B, m, e.x);
     m0.z = (uint32_t)ooff;
     m0.w = (uint32_t)(ooff >> 32);
     emit_item<KT, SUB_LDS>(P, B, lds_sub, gsub, m, m0, m1, e.x, e.y, act);
@@ -1715,13 +1800,15 @@ void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B, fast ? 1u : 0u);
 }
 uint32_t scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
-void launch_scan(const DevBatch& B, uint64_t* bsum, hipStream_t s) {
+uint32_t record_seg_shift(uint32_t n_slots) {  // smallest shift with at most 16 segments of 2^shift blocks of 256 reads
+  const uint32_t nblk = (n_slots + 255u) >> 8;
+  uint32_t k = 0;
+  while (((nblk + (1u << k) - 1u) >> k) > 16u) k++;
+  return k;
+}
+void launch_scan(const DevBatch& B, hipStream_t s) {  // block sums of indel_kernel -> block / segment bases, text sizes
   if (!B.n_slots) return;
-  const uint32_t nm = B.paired ? 2 : 1;
-  const uint32_t nblk = scan_blocks(B.n_slots);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk, nm), dim3(SCAN_BLOCK), 0, s, B.reclen, B.n_slots, bsum, nblk);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(nm), dim3(1024), 0, s, bsum, nblk, B.totals);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk, nm), dim3(SCAN_BLOCK), 0, s, B.reclen, B.n_slots, bsum, nblk, B.recoff);
+  hipLaunchKernelGGL(block_base_kernel, dim3(16, B.paired ? 2 : 1), dim3(1024), 0, s, B);
 }
 // exclusive scan of n u32 values into u64 offsets (one row); total -> *total
 void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* out, uint64_t* total, hipStream_t s) {
