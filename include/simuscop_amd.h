@@ -165,8 +165,11 @@ typedef struct sg_batch {
 int sg_plan(sg_ctx* ctx, const sg_batch* batch);
 
 /* ---- run ----------------------------------------------------------------------------------- */
-/* Enqueue the whole pass (plan draws, indel pass, offset scan, base/quality sampling + FASTQ
- * formatting) for the planned batch.  Results stay in device memory.                            */
+/* Enqueue the whole pass (plan draws, indel pass, record offsets, base/quality sampling + FASTQ
+ * formatting) for the planned batch.  Results stay in device memory.  A context that already holds
+ * output buffers (any pass but its first) queues the pass without waiting for anything: what the
+ * pass reports -- SG_ERR_OVERFLOW for a read with more than SG_MAX_EVENTS sequencing indels -- then
+ * comes from sg_result / sg_fetch instead.                                                       */
 int sg_sample(sg_ctx* ctx);
 /* Wait for the pass and report sizes: FASTQ bytes for mate 1 / mate 2 (0 for SE) and the number
  * of fragments actually produced (pairs for PE, reads for SE).                                   */
@@ -256,8 +259,8 @@ void sg_windows_drop(sg_ctx* ctx);  /* frees every window-weight store of the co
 #define SG_K_COUNT 6
 /* ---- block-gzip sink ------------------------------------------------------------ */
 /* After sg_result: compress the FASTQ text of the pass on the device into BGZF blocks -- independent
- * gzip members of 32 KB of text each (RFC 1952 with the 'BC' extra field), literal-only dynamic-Huffman
- * DEFLATE, one code per mate and pass.  Concatenated in order (and closed with sg_bgzf_eof) they form
+ * gzip members of 32 KB of text each (RFC 1952 with the 'BC' extra field), one dynamic-Huffman DEFLATE block
+ * of literals and matches (copies of earlier text of the member, runs), one pair of codes per mate and pass.  Concatenated in order (and closed with sg_bgzf_eof) they form
  * a .fq.gz file that `zcat` turns back into exactly the text sg_fetch returns.  SeqWriter::write
  * (lib/seqwriter/SeqWriter.cpp:41-54) has no such mode: additive.                                   */
 int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2);

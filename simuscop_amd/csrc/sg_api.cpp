@@ -136,6 +136,9 @@ struct sg_ctx {
   std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
   uint64_t host_flags[2] = {0, 0};  // totals[3..4] after the emit kernels: flags, slow-queue counts
+  uint64_t* mail = nullptr;         // pinned: where a pass's totals[0..4] land (copied to the two arrays above by finish_pass)
+  bool pass_pending = false;        // a pass is queued whose totals have not been looked at yet
+  bool speculative = false;         // ... and its emit kernels were launched before the text size was known (see run_pass)
   uint64_t slow_items = 0;
   bool slow_overflow = false;
   bool results_valid = false;
@@ -275,6 +278,8 @@ int sg_create(sg_ctx** out, int device, uint64_t seed) {
   e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return SG_ERR_HIP; }
   ctx->stream = ctx->own_stream;
+  e = hipHostMalloc((void**)&ctx->mail, 64, hipHostMallocDefault);
+  if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return SG_ERR_HIP; }
   *out = ctx;
   return SG_OK;
 }
@@ -299,6 +304,7 @@ void sg_destroy(sg_ctx* ctx) {
   if (ctx->evs_created)
     for (auto& ev : ctx->evs) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->mail) (void)hipHostFree(ctx->mail);
   delete ctx;
 }
 
@@ -997,39 +1003,10 @@ int sg_plan(sg_ctx* ctx, const sg_batch* b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int run_pass(sg_ctx* ctx) {
+// header + emit kernels of the current batch into the context's output buffers
+static int launch_text(sg_ctx* ctx, bool prof) {
   sg::DevBatch& B = ctx->B;
-  B.k0 = (uint32_t)ctx->seed;
-  B.k1 = (uint32_t)(ctx->seed >> 32);
-  // timing ablations (outputs are wrong when set): SG_DIAG selects the generic emit kernel, SG_FDIAG keeps the straight-line one
-  { const char* dg = getenv("SG_DIAG"); B.diag = dg ? (uint32_t)atoi(dg) : 0u; }
-  if (const char* fd = getenv("SG_FDIAG")) B.diag = (uint32_t)atoi(fd);
   hipStream_t s = ctx->stream;
-  const bool prof = ctx->profiling;
-  SG_HIP(hipMemsetAsync(B.totals, 0, sg::kTotalsBytes, s));
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
-  sg::launch_plan(ctx->P, B, s);
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));
-  sg::launch_namebase(B, s);
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[2], s));
-  sg::launch_indel(ctx->P, B, s);
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[3], s));
-  sg::launch_scan(B, s);
-  if (prof) SG_HIP(hipEventRecord(ctx->evs[4], s));
-  SG_HIP(hipGetLastError());
-  // The FASTQ size is only known now.  Reading two u64 back costs one stream sync per batch
-  // (a batch is a whole chromosome); the output buffers then grow if needed.
-  SG_HIP(hipMemcpyAsync(ctx->host_totals, B.totals, 4 * 8, hipMemcpyDeviceToHost, s));
-  SG_HIP(hipStreamSynchronize(s));
-  if (ctx->host_totals[3] & 1) return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
-  if (!ctx->out1.p && !ctx->out2.p && !ctx->gz1.p && !ctx->gz2.p && !ctx->spare.empty()) {
-    // a released output set (sg_release_outputs): its buffers become this pass's
-    sg_outputs* o = ctx->spare.back();
-    std::swap(ctx->out1, o->text[0]); std::swap(ctx->out2, o->text[1]);
-    std::swap(ctx->gz1, o->gz[0]); std::swap(ctx->gz2, o->gz[1]);
-  }
-  SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
-  if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
   B.out[0] = ctx->out1.as<uint8_t>();
   B.out[1] = ctx->out2.as<uint8_t>();
   B.out_cap[0] = ctx->out1.cap;
@@ -1052,11 +1029,81 @@ static int run_pass(sg_ctx* ctx) {
   sg::launch_header(ctx->P, B, s);
   sg::launch_emit(ctx->P, B, s, false, prof ? ctx->evs[7] : nullptr);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[6], s));
-  SG_HIP(hipMemcpyAsync(ctx->host_flags, B.totals + 3, 2 * 8, hipMemcpyDeviceToHost, s));
+  return SG_OK;
+}
+
+static int run_pass(sg_ctx* ctx) {
+  sg::DevBatch& B = ctx->B;
+  B.k0 = (uint32_t)ctx->seed;
+  B.k1 = (uint32_t)(ctx->seed >> 32);
+  // timing ablations (outputs are wrong when set): SG_DIAG selects the generic emit kernel, SG_FDIAG keeps the straight-line one
+  { const char* dg = getenv("SG_DIAG"); B.diag = dg ? (uint32_t)atoi(dg) : 0u; }
+  if (const char* fd = getenv("SG_FDIAG")) B.diag = (uint32_t)atoi(fd);
+  hipStream_t s = ctx->stream;
+  const bool prof = ctx->profiling;
+  SG_HIP(hipMemsetAsync(B.totals, 0, sg::kTotalsBytes, s));
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
+  sg::launch_plan(ctx->P, B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));
+  sg::launch_namebase(B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[2], s));
+  sg::launch_indel(ctx->P, B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[3], s));
+  sg::launch_scan(B, s);
+  if (prof) SG_HIP(hipEventRecord(ctx->evs[4], s));
+  SG_HIP(hipGetLastError());
+  if (!ctx->out1.p && !ctx->out2.p && !ctx->gz1.p && !ctx->gz2.p && !ctx->spare.empty()) {
+    // a released output set (sg_release_outputs): its buffers become this pass's
+    sg_outputs* o = ctx->spare.back();
+    std::swap(ctx->out1, o->text[0]); std::swap(ctx->out2, o->text[1]);
+    std::swap(ctx->gz1, o->gz[0]); std::swap(ctx->gz2, o->gz[1]);
+  }
+  // The FASTQ size is only known now, on the device.  When the context already holds output buffers (every pass
+  // but a context's first), the emit kernels are launched at once: they compare the size with the buffers' capacity
+  // themselves and do nothing but raise a flag when it does not fit (finish_pass then grows the buffers and launches
+  // them again).  Otherwise two u64 are read back first -- one stream sync in the middle of the pass.
+  ctx->speculative = ctx->out1.p != nullptr && (!B.paired || ctx->out2.p != nullptr) && getenv("SG_NO_SPECULATION") == nullptr;
+  if (!ctx->speculative) {
+    SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 4 * 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipStreamSynchronize(s));
+    memcpy(ctx->host_totals, ctx->mail, 4 * 8);
+    if (ctx->host_totals[3] & 1) return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
+    SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
+    if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
+  }
+  if (int rc = launch_text(ctx, prof)) return rc;
+  SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 5 * 8, hipMemcpyDeviceToHost, s));
   SG_HIP(hipGetLastError());
   ctx->sampled = true;
+  ctx->pass_pending = true;
   ctx->results_valid = false;
   ctx->gz_valid = false;
+  return SG_OK;
+}
+
+// What a queued pass left: sizes, flags; the emit kernels again if the text did not fit the buffers they were given.
+static int finish_pass(sg_ctx* ctx) {
+  if (!ctx->pass_pending) return SG_OK;
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->pass_pending = false;
+  memcpy(ctx->host_totals, ctx->mail, 4 * 8);
+  ctx->host_flags[0] = ctx->mail[3];
+  ctx->host_flags[1] = ctx->mail[4];
+  if (ctx->host_totals[3] & 1) {
+    ctx->sampled = false;
+    return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
+  }
+  if (ctx->speculative && (ctx->host_flags[0] & 4)) {  // the buffers were too small: grow, emit again
+    sg::DevBatch& B = ctx->B;
+    SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
+    if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
+    SG_HIP(hipMemsetAsync(B.totals + 3, 0, 8, ctx->stream));
+    if (int rc = launch_text(ctx, false)) return rc;
+    SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SG_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->host_flags[0] = ctx->mail[3];
+    ctx->host_flags[1] = ctx->mail[4];
+  }
   return SG_OK;
 }
 
@@ -1084,6 +1131,7 @@ int sg_result(sg_ctx* ctx, uint64_t* bytes_r1, uint64_t* bytes_r2, uint64_t* n_f
   if (!ctx) return SG_ERR_INVALID;
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_result: call sg_sample first");
   SG_HIP(hipSetDevice(ctx->device));
+  if (int rc = finish_pass(ctx)) return rc;
   SG_HIP(hipStreamSynchronize(ctx->stream));
   if (!ctx->results_valid) {
     ctx->slow_items = (ctx->host_flags[1] & 0xFFFFFFFFu) + (ctx->host_flags[1] >> 32);
@@ -1110,6 +1158,7 @@ int sg_fetch(sg_ctx* ctx, char* host_r1, char* host_r2) {
   if (!ctx) return SG_ERR_INVALID;
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_fetch: call sg_sample first");
   SG_HIP(hipSetDevice(ctx->device));
+  if (int rc = finish_pass(ctx)) return rc;
   if (host_r1 && ctx->host_totals[0])
     SG_HIP(hipMemcpyAsync(host_r1, ctx->out1.p, ctx->host_totals[0], hipMemcpyDeviceToHost, ctx->stream));
   if (host_r2 && ctx->B.paired && ctx->host_totals[1])
@@ -1122,6 +1171,8 @@ int sg_fetch_range(sg_ctx* ctx, int mate, uint64_t offset, uint64_t bytes, char*
   if (!ctx || (bytes && !host_dst) || mate < 0 || mate > 1) return SG_ERR_INVALID;
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: call sg_sample first");
   if (mate == 1 && !ctx->B.paired) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: single-end batch has no mate 2");
+  SG_HIP(hipSetDevice(ctx->device));
+  if (int rc = finish_pass(ctx)) return rc;
   if (offset + bytes > ctx->host_totals[mate]) return ctx->fail(SG_ERR_INVALID, "sg_fetch_range: range past the end of the FASTQ text");
   if (!bytes) return SG_OK;
   SG_HIP(hipSetDevice(ctx->device));

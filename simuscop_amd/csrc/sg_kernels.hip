@@ -885,6 +885,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
+  // launched before the host knew the text size (sg_api.cpp run_pass): a text that does not fit the buffers is left to
+  // a second launch into larger ones
+  if (B.totals[m] + 64u > B.out_cap[m]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr((unsigned long long*)&B.totals[3], 4ull);
+    return;
+  }
   const uint32_t tm = B.paired ? m : 0u;  // SE always samples from the mate-1 tables (Segment.cpp:770,777)
   // ---- LDS carve-up: [sub rows][per-wave metadata rows]; the alias columns are read through L2 ----
   uint4* lds_sub = smem;
@@ -1206,6 +1212,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
   const uint32_t tm = PAIRED ? m : 0u;
+  // launched before the host knew the text size (sg_api.cpp run_pass): a text that does not fit the buffers is left to
+  // a second launch into larger ones
+  if (B.totals[m] + 64u > B.out_cap[m]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr((unsigned long long*)&B.totals[3], 4ull);
+    return;
+  }
   const uint32_t bins = (uint32_t)P.bins;
   // ---- LDS: [table image: bins x fast_stride words][look-up rows: TI x 12][256 words: four 2-bit codes -> bytes code * 4]
   //           [per-wave read rows][slow-item queues][fix-up lists][read order][appended items] ----

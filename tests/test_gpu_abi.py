@@ -209,3 +209,33 @@ def test_detached_outputs_survive_the_next_pass(tmp_path):
         assert sess.fetch(d1, d2) == (t1, t2)
     finally:
         sess.close()
+
+
+def test_a_pass_larger_than_the_buffers_it_was_launched_into(tmp_path, monkeypatch):
+    """Every pass but a context's first is queued without waiting for the text size (the emit kernels are launched into
+    the buffers the context holds and check the capacity themselves).  A small chromosome first, then the largest one:
+    the second pass does not fit, is emitted again into grown buffers, and equals what the same sequence of passes gives
+    when every pass waits for its size (SG_NO_SPECULATION)."""
+    cfg = cases.build_case("c3_grch38_pe_xten_cov3", str(tmp_path))
+
+    def texts_of(chroms):
+        sess = simuscop_amd.Session(cfg, device=0, write_files=0, quiet=1, seed=31)
+        try:
+            sess.weighted_length()
+            sess.set_reads(sess.planned_reads)
+            out = []
+            for c in chroms:
+                assert sess.prepare_batch(c)
+                sess.sample()
+                b1, b2, nf = sess.result()
+                out.append((b1, b2, nf, hashlib.md5(b"".join(sess.fetch(b1, b2))).hexdigest()))
+            return out
+        finally:
+            sess.close()
+
+    order = [20, 0, 21, 1]                  # chr21 (smallest), chr1, chr22, chr2
+    queued = texts_of(order)
+    monkeypatch.setenv("SG_NO_SPECULATION", "1")
+    waited = texts_of(order)
+    assert queued == waited
+    assert queued[1][0] > 4 * queued[0][0] and queued[3][0] > 4 * queued[2][0]
