@@ -24,6 +24,7 @@ void launch_namebase(const DevBatch& B, hipStream_t s);
 void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s);
 uint32_t scan_blocks(uint32_t n);
 void launch_scan(const DevBatch& B, hipStream_t s);
+void launch_mail(const uint64_t* totals, uint64_t* mail, hipStream_t s);
 uint32_t record_seg_shift(uint32_t n_slots);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s);
 void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool force_generic, hipEvent_t after_main);
@@ -1041,7 +1042,7 @@ static int run_pass(sg_ctx* ctx) {
   if (const char* fd = getenv("SG_FDIAG")) B.diag = (uint32_t)atoi(fd);
   hipStream_t s = ctx->stream;
   const bool prof = ctx->profiling;
-  SG_HIP(hipMemsetAsync(B.totals, 0, sg::kTotalsBytes, s));
+  if (!B.n_windows) SG_HIP(hipMemsetAsync(B.totals, 0, sg::kTotalsBytes, s));  // (otherwise plan_kernel clears them)
   if (prof) SG_HIP(hipEventRecord(ctx->evs[0], s));
   sg::launch_plan(ctx->P, B, s);
   if (prof) SG_HIP(hipEventRecord(ctx->evs[1], s));
@@ -1064,7 +1065,7 @@ static int run_pass(sg_ctx* ctx) {
   // them again).  Otherwise two u64 are read back first -- one stream sync in the middle of the pass.
   ctx->speculative = ctx->out1.p != nullptr && (!B.paired || ctx->out2.p != nullptr) && getenv("SG_NO_SPECULATION") == nullptr;
   if (!ctx->speculative) {
-    SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 4 * 8, hipMemcpyDeviceToHost, s));
+    sg::launch_mail(B.totals, ctx->mail, s);
     SG_HIP(hipStreamSynchronize(s));
     memcpy(ctx->host_totals, ctx->mail, 4 * 8);
     if (ctx->host_totals[3] & 1) return ctx->fail(SG_ERR_OVERFLOW, "sg_sample: a read drew more than SG_MAX_EVENTS sequencing indels");
@@ -1072,7 +1073,7 @@ static int run_pass(sg_ctx* ctx) {
     if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
   }
   if (int rc = launch_text(ctx, prof)) return rc;
-  SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 5 * 8, hipMemcpyDeviceToHost, s));
+  sg::launch_mail(B.totals, ctx->mail, s);
   SG_HIP(hipGetLastError());
   ctx->sampled = true;
   ctx->pass_pending = true;
@@ -1099,7 +1100,7 @@ static int finish_pass(sg_ctx* ctx) {
     if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
     SG_HIP(hipMemsetAsync(B.totals + 3, 0, 8, ctx->stream));
     if (int rc = launch_text(ctx, false)) return rc;
-    SG_HIP(hipMemcpyAsync(ctx->mail, B.totals, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    sg::launch_mail(B.totals, ctx->mail, ctx->stream);
     SG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->host_flags[0] = ctx->mail[3];
     ctx->host_flags[1] = ctx->mail[4];

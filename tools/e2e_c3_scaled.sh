@@ -7,7 +7,7 @@ python - <<PY
 import sys, time; sys.path.insert(0,'.')
 from simuscop_amd import synth
 t=time.time(); synth.write_fasta('$W/ref.fa', synth.grch38_contigs(${SCALE:-0.1}), seed=38); print('fasta %.1fs' % (time.time()-t))
-open('$W/config.txt','w').write("ref = $W/ref.fa\nprofile = tests/golden/testData/Illumina_HiSeqXTen.profile\nname = sim\noutput = $W/out\nlayout = PE\nthreads = 16\nverbose = 0\ncoverage = ${COVERAGE:-30}\ninsertSize = 350\n")
+open('$W/config.txt','w').write("ref = $W/ref.fa\nprofile = tests/golden/testData/Illumina_HiSeqXTen.profile\nname = sim\noutput = $W/out\nlayout = PE\nthreads = ${THREADS:-16}\nverbose = 0\ncoverage = ${COVERAGE:-30}\ninsertSize = 350\n")
 PY
 IFS=";" read -ra MODES_ARR <<< "${MODES:---no-write;--no-write;--no-write --host-haplotypes;--no-write --fetch}"
 for mode in "${MODES_ARR[@]}"; do
