@@ -254,7 +254,7 @@ struct Profile {
   int N = 4, kmer = 0, bins = 0, readLength = 0, kmerCount = 0;
   int minQ = 33, maxQ = 126, nQual = 94;
   double insertRate = 0, delRate = 0, stdISize = 0, gcStd = 0;
-  uint64_t cntIns = 0, cntDel = 0;  // philox mode: see ReadCtx::indel_event (set by countIndelDraws)
+  uint64_t cntIns = 0, cntDel = 0;  // philox mode: the numbers of 32-bit draws passing the two tests (countIndelDraws), see buildIndelGaps
   void countIndelDraws() {
     // number of 32-bit draws x with x/2^32 <= insertRate, resp. x/2^32 < delRate/(1-insertRate): both
     // predicates are monotone in x, so a bisection over [0, 2^32] finds the exact counts
@@ -270,6 +270,25 @@ struct Profile {
     };
     cntIns = count(false, insertRate);
     cntDel = count(true, dthr);
+    buildIndelGaps();
+  }
+  // philox mode: sequencing indels by skipping ahead.  With A = cntIns * 2^32 and B = A + (2^32 - cntIns) * cntDel
+  // (in units of 2^-64) a template position carries an indel candidate with probability B / 2^64 -- an insertion with
+  // probability A / B, else a deletion -- independently of every other position (Profile.cpp:1560-1570 draws them one
+  // position at a time).  The distance to the next candidate is therefore geometric, and it is drawn directly:
+  //   gapS[k] = P(no candidate in the next k positions) * 2^64:  gapS[1] = 2^64 - B,  gapS[k+1] = floor(gapS[k] * gapS[1] / 2^64)
+  //   one 64-bit uniform x:  g = #{k >= 1 : x < gapS[k]}  positions are skipped, the candidate sits on the next one.
+  // (The floors make P(g >= k) differ from (1 - B/2^64)^k by less than k * 2^-64.)
+  uint64_t evA = 0, evB = 0;
+  vector<uint64_t> gapS;  // [0 .. readLength]; [0] unused
+  void buildIndelGaps() {
+    evA = cntIns << 32;
+    evB = evA + ((1ull << 32) - cntIns) * cntDel;
+    const int L = std::max(readLength, 1);
+    gapS.assign((size_t)L + 1, 0xFFFFFFFFFFFFFFFFull);
+    if (evB == 0) return;  // no candidates ever (x < 2^64 - 1 for every draw but one)
+    gapS[1] = 0ull - evB;
+    for (int k = 1; k < L; k++) gapS[(size_t)k + 1] = (uint64_t)(((unsigned __int128)gapS[(size_t)k] * gapS[1]) >> 64);
   }
   // ---- philox mode: integer sampling tables (built from the fp64 CDFs by buildIntegerTables) ----
   // Substitution row (kmerIndx, bin): outcomes in the order o = [cd, the other base indexes ascending], cd = index of the
@@ -655,23 +674,18 @@ struct ReadCtx {
     (void)j; (void)which;
     return rng->realGen();
   }
-  // philox mode: the insert test and the deletion test of template position j decided by ONE 64-bit
-  // uniform x64 with exactly the joint distribution of the reference's two 32-bit draws
-  // (Profile.cpp:1560-1570): with cntIns = #{x : x/2^32 <= insertRate} and cntDel = #{x : x/2^32 <
-  // delRate/(1-insertRate)}, P(insert) = cntIns/2^32 and P(delete) = (1 - cntIns/2^32) * cntDel/2^32, so
-  //   insert  iff  x64 <  cntIns * 2^32,        delete  iff  cntIns * 2^32 <= x64 < cntIns * 2^32 + (2^32 - cntIns) * cntDel.
-  // x64 = head16 << 48 | tail48: the heads of eight positions are the 16-bit halves of call (j/8, c2 = 0)
-  // (word p/2, low half for even p), the tails of positions 2q, 2q+1 the low 48 bits of words (0,1) and
-  // (2,3) of call (j/8, c2 = 1 + q) -- a consumer needs the tail only when the head sits on a boundary.
-  int indel_event(int j, uint64_t cntIns, uint64_t cntDel) {  // 0 none, 1 insertion, 2 deletion
-    const uint32_t p = (uint32_t)j & 7u;
-    const uint32_t hw = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 0, p >> 1);
-    const uint64_t head = (hw >> (16u * (p & 1u))) & 0xFFFFu;
-    const uint32_t t0 = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 1u + (p >> 1), (p & 1u) * 2u);
-    const uint32_t t1 = rng->ph(KIND_INDEL, ctx24(), slot, (uint32_t)(j >> 3), 1u + (p >> 1), (p & 1u) * 2u + 1u);
-    const uint64_t x64 = (head << 48) | ((uint64_t)(t1 & 0xFFFFu) << 32) | t0;
-    const uint64_t a64 = cntIns << 32, b64 = a64 + ((1ull << 32) - cntIns) * cntDel;
-    return x64 < a64 ? 1 : (x64 < b64 ? 2 : 0);
+  // philox mode (Profile::buildIndelGaps): the e-th candidate of the read, looked for from template position `start`.
+  // Call (KIND_INDEL, c0 = slot, c1 = e, c2 = 0): x = words (1,0) -> distance, y = words (3,2) -> kind.
+  // Returns the candidate's position (n: none before the read's end) and its kind (1 insertion, 2 deletion).
+  int indel_candidate(uint32_t e, int start, int n, const vector<uint64_t>& gapS, uint64_t evA, uint64_t evB, int* kind) {
+    const uint64_t x = ((uint64_t)rng->ph(KIND_INDEL, ctx24(), slot, e, 0, 1) << 32) | rng->ph(KIND_INDEL, ctx24(), slot, e, 0, 0);
+    const uint64_t y = ((uint64_t)rng->ph(KIND_INDEL, ctx24(), slot, e, 0, 3) << 32) | rng->ph(KIND_INDEL, ctx24(), slot, e, 0, 2);
+    const int room = n - start;  // >= 1
+    if (x < gapS[(size_t)room]) return n;
+    int g = 0;
+    while (g + 1 < room && x < gapS[(size_t)g + 1]) g++;
+    *kind = (uint64_t)(((unsigned __int128)y * evB) >> 64) < evA ? 1 : 2;
+    return start + g;
   }
   uint32_t aux(int j, int f, bool intStream) {  // f=0 indel length (real), f>=1 inserted base f-1 (int)
     if (!rng->philox) return intStream ? rng->intGen() : rng->realGen();
@@ -708,16 +722,20 @@ static int predict(const Profile& P, const char* refSeq, int n, int isRead1, Rea
   map<int, vector<int>> indelBaseIndxs;
   vector<int> indelLens;
   int indelLength = 0;
+  // philox mode: the next candidate position and its kind (drawn ahead, see Profile::buildIndelGaps)
+  uint32_t candOrd = 0;
+  int candPos = n, candKind = 0;
+  if (rc.rng->philox && n > 0) candPos = rc.indel_candidate(candOrd++, 0, n, P.gapS, P.evA, P.evB, &candKind);
   for (int j = 0; j < n;) {
     // getIndelSeq(indelBaseIndxs[j])
     vector<int>& baseIndxs = indelBaseIndxs[j];
     baseIndxs.clear();
     int k = 0;
     bool isIns, isDel = false;
+    const bool atCand = rc.rng->philox && j == candPos;
     if (rc.rng->philox) {
-      const int ev = rc.indel_event(j, P.cntIns, P.cntDel);
-      isIns = ev == 1;
-      isDel = ev == 2;
+      isIns = atCand && candKind == 1;
+      isDel = atCand && candKind == 2;
     } else {
       double p = u32ToDouble(rc.indel(j, 0), 0, 1);
       isIns = p <= P.insertRate;
@@ -744,6 +762,7 @@ static int predict(const Profile& P, const char* refSeq, int n, int isRead1, Rea
       j++;
       indelLens.push_back(k);
     }
+    if (atCand) candPos = j < n ? rc.indel_candidate(candOrd++, j, n, P.gapS, P.evA, P.evB, &candKind) : n;
   }
   if (n + indelLength < 50) {
     indelLength = 0;

@@ -177,9 +177,7 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   SG_ENSURE(ctx->pairs, ((size_t)n_slots + 1) * sizeof(sg::PairRec));
   SG_ENSURE(ctx->win_actual, (nw + 1) * 4);
   SG_ENSURE(ctx->win_namebase, (nw + 1) * 4);
-  SG_ENSURE(ctx->rlen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
-  SG_ENSURE(ctx->reclen, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 4);
   SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
   SG_ENSURE(ctx->totals, sg::kTotalsBytes);
@@ -205,9 +203,7 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   B.pairs = ctx->pairs.as<sg::PairRec>();
   B.win_actual = ctx->win_actual.as<uint32_t>();
   B.win_namebase = ctx->win_namebase.as<uint32_t>();
-  B.rlen = ctx->rlen.as<uint32_t>();
   B.events = ctx->events.as<uint32_t>();
-  B.reclen = ctx->reclen.as<uint32_t>();
   B.recloc = ctx->recoff.as<uint32_t>();
   B.blkbase = ctx->bsum.as<uint64_t>();
   B.seg_shift = sg::record_seg_shift((uint32_t)n_slots);
@@ -443,6 +439,28 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   add_row(pr->del_cdf, pr->n_del, del_off, del_lg);
   const bool has_isz = pr->isize_cdf != nullptr && pr->n_isize > 0;
   if (has_isz) add_row(pr->isize_cdf, pr->n_isize, isz_off, isz_lg);
+  // Sequencing indels by skipping ahead: getIndelSeq tests every template position with `p <= insertRate`, then
+  // `p < delRate/(1-insertRate)`, p = x/2^32 (Profile.cpp:1560-1570).  cI, cD = the numbers of 32-bit draws that pass;
+  // a position is a candidate with probability evB / 2^64, evB = cI 2^32 + (2^32 - cI) cD, an insertion with evA / evB,
+  // evA = cI 2^32.  gap[k] = floor(gap[k-1] * gap[1] / 2^64), gap[1] = 2^64 - evB: P(no candidate in k positions).
+  if (pr->insert_rate < 0) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: negative insert rate");
+  const uint64_t ci = sg::count_unit_le(pr->insert_rate);
+  const uint64_t cd = sg::count_unit_lt(pr->del_rate / (1 - pr->insert_rate));
+  if (ci >= (1ull << 31) || cd >= (1ull << 31)) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: sequencing indel rate >= 0.5");
+  const uint64_t evA = ci << 32, evB = evA + ((1ull << 32) - ci) * cd;
+  while (tab.size() % 4) tab.push_back(0);
+  const size_t gap_off = tab.size();
+  {
+    const int L = std::max(pr->read_length, 1);
+    std::vector<uint64_t> gap((size_t)L + 1, 0xFFFFFFFFFFFFFFFFull);
+    if (evB) {
+      gap[1] = 0ull - evB;
+      for (int k = 1; k < L; k++) gap[(size_t)k + 1] = (uint64_t)(((unsigned __int128)gap[(size_t)k] * gap[1]) >> 64);
+    }
+    tab.resize(gap_off + 2 * gap.size());
+    memcpy(&tab[gap_off], gap.data(), gap.size() * 8);
+    while (tab.size() % 4) tab.push_back(0);
+  }
   // Straight-line kernel tables (kmer 3).  The kernel packs base codes 2 bits each in NATURAL order (A0 C1 T2 G3) with
   // the OLDEST base of a context in the lowest digit; the reference numbers a context with its oldest base in the
   // highest digit, in `bases` order (Profile::initKmers).  Context ids of the kernel: [0,4) one base, [4,20) two, [20,84)
@@ -543,14 +561,8 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   P.fixed_isz = pr->insert_size;
   P.isz_lo = has_isz ? pr->isize_min : pr->insert_size;
   P.isz_hi = has_isz ? pr->isize_min + pr->n_isize - 1 : pr->insert_size;
-  // getIndelSeq: `p <= insertRate`, then `p < delRate/(1-insertRate)` with p = x/2^32 (Profile.cpp:1560-1570)
-  uint64_t ci = sg::count_unit_le(pr->insert_rate);
-  P.Tins = (uint32_t)(ci - 1);  // ci >= 1 for any rate >= 0
-  if (pr->insert_rate < 0) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: negative insert rate");
-  double d = pr->del_rate / (1 - pr->insert_rate);
-  uint64_t cd = sg::count_unit_lt(d);
-  if (cd > 0xFFFFFFFFull) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: deletion rate >= 1");
-  P.Cdel = (uint32_t)cd;
+  P.evA = evA; P.evB = evB;
+  P.gap_row = (const uint64_t*)(base + gap_off);
   P.L = pr->read_length; P.bins = bins; P.kmer = pr->kmer; P.min_qual = pr->min_qual;
   P.remap_packed = remap; P.bases_packed = packed;
   {

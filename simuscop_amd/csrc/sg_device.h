@@ -45,8 +45,10 @@ struct DevProfile {
   const uint32_t* isz_row; uint32_t isz_lg;  // isz_row == nullptr -> fixed insert size
   int32_t isz_min, fixed_isz;
   int32_t isz_lo, isz_hi;      // smallest / largest insert size that can be drawn
-  uint32_t Tins;               // insertion iff x <= Tins
-  uint32_t Cdel;               // deletion  iff x <  Cdel
+  // sequencing indels by skipping ahead (indel_kernel): evA / 2^64 = P(insertion at a position), evB / 2^64 = P(insertion or
+  // deletion); gap_row[k] = P(no candidate in the next k positions) * 2^64, k = 1 .. L ([0] unused)
+  uint64_t evA, evB;
+  const uint64_t* gap_row;
   int32_t L, bins, kmer, min_qual;
   uint32_t remap_packed;       // natural index (A0 C1 T2 G3) -> profile base code, 2 bits each
   uint32_t bases_packed;       // profile base code -> ASCII, 8 bits each
@@ -82,9 +84,7 @@ struct DevBatch {
   PairRec* pairs;               // [n_slots]
   uint32_t* win_actual;         // [n_windows] fragments actually produced per window
   uint32_t* win_namebase;       // [n_windows] fragments produced by earlier windows of the same segment
-  uint32_t* rlen;               // [2][n_slots]  n' | nev<<16
   uint32_t* events;             // [2][n_slots][SG_MAX_EVENTS]
-  uint32_t* reclen;             // [2][n_slots] FASTQ record bytes
   uint32_t* recloc;             // [2][n_slots] exclusive prefix of reclen inside the read's block of 256 (indel_kernel)
   uint64_t* blkbase;            // [2][ceil(n_slots / 256)] offset of a block's first record inside its segment of 2^seg_shift blocks
                                 // (sums by indel_kernel, scanned in place by block_base_kernel; the segments' own bases: totals + kTotalsSegBase)

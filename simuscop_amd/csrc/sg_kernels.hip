@@ -214,6 +214,14 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
       if ((q >> 2) < n_rows) dst[q] = wave_rows[q];
     }
   };
+  // the table of the indel distances (see below), staged by the whole block before any wave can leave
+  __shared__ uint64_t gap_lds[256];
+  const uint64_t* gap = P.gap_row;
+  if ((uint32_t)P.L + 1u <= 256u) {  // (longer reads: from L2)
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)P.L; i += blockDim.x) gap_lds[i] = P.gap_row[i];
+    gap = gap_lds;
+    __syncthreads();
+  }
   const bool in_batch = t < B.n_slots;
   const size_t idx = (size_t)m * B.n_slots + (in_batch ? t : 0u);
   PairRec rec = {};
@@ -243,14 +251,12 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     if (threadIdx.x == 0) B.blkbase[(size_t)m * gridDim.x + blockIdx.x] = all;
   };
   if (__ballot(flen != 0u) == 0ull) {  // nothing planned in the whole wave
-    if (in_batch) { B.rlen[idx] = 0; B.reclen[idx] = 0; }
     my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
     if (t_wave < B.n_slots) store_rows();
     block_prefix();
     return;
   }
   if (!flen) {
-    if (in_batch) { B.rlen[idx] = 0; B.reclen[idx] = 0; }
     my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
   }
   // (lanes without a fragment stay in the kernel for the wave-wide steps below, doing nothing in between)
@@ -260,38 +266,45 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   uint32_t nev = 0, first_ev = 0;
   uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
   const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
-  // The insert test and the deletion test of a template position (Profile.cpp:1560-1570: two 32-bit draws,
-  // P(ins) = cI / 2^32, P(del) = (1 - cI / 2^32) * cD / 2^32) are decided by ONE 64-bit uniform with exactly
-  // that joint distribution:  ins iff x64 < A,  del iff A <= x64 < B,  A = cI * 2^32, B = A + (2^32 - cI) * cD.
-  // x64 = head16 << 48 | tail48; the heads of eight positions are the halves of the four words of call (c, 0),
-  // the tail (call (c, 1 + p/2)) is needed only when a head equals the head of A or of B (2 in 65536).  A call
-  // ends after eight compares unless some lane of the wave has a head at or below B's (a quarter of a wave's
-  // calls, almost always a real event); then only the flagged positions are walked.
-  const uint64_t cI = (uint64_t)P.Tins + 1ull, A64 = cI << 32, B64 = A64 + ((1ull << 32) - cI) * (uint64_t)P.Cdel;
-  const uint32_t hA = (uint32_t)(A64 >> 48), hB = (uint32_t)(B64 >> 48);
-  // One chunk of eight positions: the flagged ones are walked in order (j = first position not covered by a deletion
-  // so far).  Rare work: run for the few lanes that have a candidate, after the scan below.
-  auto walk_chunk = [&](int c, const uint32_t (&x)[4]) {
-    uint32_t cand = 0;
-#pragma unroll
-    for (int p = 0; p < 8; p++) cand |= (uint32_t)(((x[p >> 1] >> (16 * (p & 1))) & 0xFFFFu) <= hB) << p;
+  // Sequencing indels by skipping ahead (DevProfile::gap_row): every template position is an indel candidate with
+  // probability evB / 2^64, independently, so the distance to the next one is geometric and is drawn directly -- call
+  // (slot, e, 0) of the read's e-th candidate: x = words (1, 0) against the table P(no candidate in k positions),
+  // y = words (3, 2): an insertion iff floor(y evB / 2^64) < evA.  A read without indels (84 % at XTen rates) costs ONE
+  // call and ONE compare (x < gap[L]); testing every position took 19 calls per 151-base read.
+  // What the read's row needs from its window, fetched BEFORE the candidate loop: three dependent gathers (window ->
+  // segment size, name base, chain offset -> bad-block bits) whose latency the loop's Philox calls then cover.
+  uint32_t namepos = 0, fragcount = 0, touches_bad = 0;
+  uint64_t foff = 0;
+  const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
+  if (live) {
+    const sg_window win = B.windows[rec.win];
+    const uint32_t pos = win.spos + rec.relpos;
+    namepos = pos % B.seg_size[win.seg];
+    fragcount = B.win_namebase[rec.win] + rec.k + 1u;
+    foff = B.chain_off[win.chain] + win.hap_base + pos;
+    // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
+    // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
+    // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
+    const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
+    for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
+  }
+  {
+    uint32_t e = 0;
 #pragma unroll 1
-    while (cand) {
-      const int p = __builtin_ctz(cand);
-      cand &= cand - 1u;
-      const int jj = 8 * c + p;
-      if (jj >= L || jj < j) continue;
-      const uint32_t w = p < 2 ? x[0] : p < 4 ? x[1] : p < 6 ? x[2] : x[3];
-      const uint32_t head = (w >> (16 * (p & 1))) & 0xFFFFu;
-      bool is_ins = head < hA, is_del = head > hA && head < hB;
-      if (head == hA || head == hB) {
-        uint32_t y[4];
-        philox4x32_10(t + B.slot_offset, (uint32_t)c, 1u + (uint32_t)(p >> 1), c3, B.k0, B.k1, y);
-        const uint64_t tail = (p & 1) ? ((uint64_t)(y[3] & 0xFFFFu) << 32) | y[2] : ((uint64_t)(y[1] & 0xFFFFu) << 32) | y[0];
-        const uint64_t x64 = ((uint64_t)head << 48) | tail;
-        is_ins = x64 < A64;
-        is_del = !is_ins && x64 < B64;
+    while (j < L) {  // (L = 0 for lanes without a fragment)
+      uint32_t x4[4];
+      philox4x32_10(t + B.slot_offset, e++, 0, c3, B.k0, B.k1, x4);
+      const uint64_t x = ((uint64_t)x4[1] << 32) | x4[0], y = ((uint64_t)x4[3] << 32) | x4[2];
+      const int room = L - j;
+      if (x < gap[room]) break;                 // no candidate before the read's end
+      int lo = 0, hi = room - 1;                // g = #{k in [1, room): x < gap[k]} (gap decreases)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (x < gap[mid]) lo = mid; else hi = mid - 1;
       }
+      const int jj = j + lo;
+      const bool is_ins = __umul64hi(y, P.evB) < P.evA;
+      j = jj + 1;
       if (is_ins) {
         uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
           nev++;
           dl += (int)len;
         }
-      } else if (is_del) {
+      } else {
         uint32_t len = row_search(P.del_row, P.del_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
         if (len > 0) {
           uint32_t k = min((uint32_t)(L - jj), len);
@@ -312,72 +325,16 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
         }
       }
     }
-  };
-  // smallest of a call's eight 16-bit heads (packed 16-bit minima)
-  auto min_head = [](const uint32_t (&x)[4]) -> uint32_t {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const u16x2 a = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x[0]), __builtin_bit_cast(u16x2, x[1]));
-    const u16x2 b2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x[2]), __builtin_bit_cast(u16x2, x[3]));
-    const u16x2 c2 = __builtin_elementwise_min(a, b2);
-    return min((uint32_t)c2.x, (uint32_t)c2.y);
-  };
-  const int nch = (L + 7) / 8;
-  if (nch <= 64) {
-    // Scan: one Philox call per chunk, nothing else -- a chunk with a head at or below B's (1 % of them) is a bit in
-    // the lane's mask.  Then the lanes with candidates walk theirs, in order, a chunk per round: the rounds (two or
-    // three per wave) serve all candidate lanes at once, where handling a candidate on the spot stalled the whole
-    // wave in a quarter of the calls.
-    unsigned long long cmask = 0;
-    for (int c = 0; c < nch; c++) {
-      uint32_t x[4];
-      philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
-      cmask |= (unsigned long long)(min_head(x) <= hB) << c;
-    }
-    while (__ballot(cmask != 0ull) != 0ull) {
-      if (cmask != 0ull) {
-        const int c = __builtin_ctzll(cmask);
-        cmask &= cmask - 1ull;
-        if (8 * c + 7 >= j) {  // not wholly consumed by a deletion
-          uint32_t x[4];
-          philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
-          walk_chunk(c, x);
-        }
-      }
-    }
-  } else {
-    for (int c = 0; c < nch; c++) {  // reads of more than 512 bases: chunk by chunk
-      if (8 * c + 7 < j) continue;
-      uint32_t x[4];
-      philox4x32_10(t + B.slot_offset, (uint32_t)c, 0, c3, B.k0, B.k1, x);
-      if (__ballot(min_head(x) <= hB) == 0ull) continue;
-      if (min_head(x) <= hB) walk_chunk(c, x);
-    }
   }
   if (live) {
     if (L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
     if (nev > SG_MAX_EVENTS) { atomicOr((unsigned long long*)&B.totals[3], 1ull); nev = 0; dl = 0; }
     const uint32_t np = (uint32_t)(L + dl);
-    B.rlen[idx] = np | (nev << 16);
-    const sg_window win = B.windows[rec.win];
-    const uint32_t pos = win.spos + rec.relpos;
-    const uint32_t namepos = pos % B.seg_size[win.seg];
-    const uint32_t fragcount = B.win_namebase[rec.win] + rec.k + 1u;
     const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
     rl = hdr + 2u * np + 4u;
-    B.reclen[idx] = rl;
     // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
     // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
     // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
-    const uint64_t foff = B.chain_off[win.chain] + win.hap_base + pos;
-    const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
-    // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
-    // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
-    // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
-    uint32_t touches_bad = 0;
-    {
-      const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
-      for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
-    }
     my_row[0] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
     // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
     // (sg_load_profile rejects profiles that could violate the bound)
@@ -429,7 +386,7 @@ __global__ __launch_bounds__(256) void header_kernel(DevBatch B, uint32_t only_l
   if (only_long && (m1.y >> 22) <= 32u) return;  // written by the emit kernel from the row
   const uint4 m0 = B.meta[idx * 4];
   const uint64_t ooff = rec_offset(B, m, t);
-  if (ooff + B.reclen[idx] > B.out_cap[m]) return;  // host re-checks totals before launching
+  if (ooff + ((m1.y >> 22) + 2u * (m1.y & 0xFFFFu) + 4u) > B.out_cap[m]) return;  // (the record's length: header + 2 lines + 4 line breaks and '+')
   const uint32_t namepos = m0.z, fragcount = m0.w;
   if (!(B.diag & 4u)) {
     // byte stream -> unaligned dword stores (7 instead of 27 byte stores per record)
