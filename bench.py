@@ -258,6 +258,11 @@ def main():
         sess.sample()
         return sess.result()   # waits for the pass (stream sync) and returns sizes
 
+    # A context's first passes are not steady state: the first one allocates the output buffers (and is the only one that
+    # waits for its size in mid-pass), code and tables page in, the clocks ramp.  Five untimed passes before the W
+    # warm-up steps of the contract, so that a run with few steps measures what a long one does.
+    for _ in range(5):
+        step()
     for _ in range(args.warmup):
         step()
     if world > 1:
