@@ -1854,6 +1854,15 @@ extern "C" void orc_profile_alias_row(const orc_profile* h, int base_pair, int b
 extern "C" void orc_profile_kmer(const orc_profile* h, int i, char* out) {
   memcpy(out, h->p.kmers[i].data(), h->p.kmer);
 }
+// philox mode: the indel candidate law (Profile::buildIndelGaps): A, B in units of 2^-64 and the first n entries of
+// the distance table gapS[1..]; returns the table's length (read length)
+extern "C" int orc_profile_indel_gaps(const orc_profile* h, uint64_t ab[2], uint64_t* gaps, int n) {
+  ab[0] = h->p.evA;
+  ab[1] = h->p.evB;
+  const int L = (int)h->p.gapS.size() - 1;
+  for (int k = 1; k <= n && k <= L; k++) gaps[k - 1] = h->p.gapS[(size_t)k];
+  return L;
+}
 extern "C" int orc_predict_philox(const orc_profile* h, const char* ref, int n, int is_read1, uint64_t seed,
                                   uint32_t batch_id, uint32_t pair_slot, char* out_bases, char* out_quals) {
   orc::Rng rng;

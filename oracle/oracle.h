@@ -53,6 +53,8 @@ void orc_profile_sub_row(const orc_profile*, int mate2, int kmer_indx, int bin, 
 void orc_profile_alias_row(const orc_profile*, int base_pair, int bin, uint32_t* thr, uint8_t* lo, uint8_t* hi);
 // kmer strings in table order (Profile::initKmers, Profile.cpp:70-124): writes kmer chars of entry i
 void orc_profile_kmer(const orc_profile*, int i, char* out);
+// indel candidates by skipping ahead: ab = {A, B} (2^-64 units), gaps[k-1] = P(no candidate in k positions) * 2^64; returns L
+int orc_profile_indel_gaps(const orc_profile*, uint64_t ab[2], uint64_t* gaps, int n);
 
 // ---- Profile::predict (Profile.cpp:1586-1701) in philox mode, for unit parity ----
 // ref: n bytes (not NUL terminated). out: caller buffer >= 2*(n+max_ins)+1. Returns read length n'.

@@ -39,6 +39,8 @@ def oracle_lib():
     lib.orc_profile_array.argtypes = [c.c_void_p, c.c_int]
     lib.orc_profile_array.restype = c.POINTER(c.c_double)
     lib.orc_profile_kmer.argtypes = [c.c_void_p, c.c_int, c.c_char_p]
+    lib.orc_profile_indel_gaps.argtypes = [c.c_void_p, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.c_int]
+    lib.orc_profile_indel_gaps.restype = c.c_int
     lib.orc_predict_philox.argtypes = [c.c_void_p, c.c_char_p, c.c_int, c.c_int, c.c_uint64, c.c_uint32,
                                        c.c_uint32, c.c_char_p, c.c_char_p]
     lib.orc_predict_philox.restype = c.c_int

@@ -106,3 +106,48 @@ def test_alias_row_edge_shapes():
     assert rc == 0 and got == _counts(lib, [2.4e-10, 1.0, 1.0]) == [2, (1 << 32) - 2, 0]
     rc, *_ = run([0.1, 0.2, 0.3, 0.4, 0.5, 1.0], 2)   # six symbols do not fit four columns
     assert rc != 0
+
+
+@pytest.mark.parametrize("prof", ["Illumina_HiSeqXTen.profile", "Illumina_GenomeAnalyzerIIx.profile"])
+def test_indel_candidates_by_skipping_ahead(prof, oracle_lib):
+    """Sequencing indels in philox mode: the distance to a read's next indel candidate is drawn from a table of
+    P(no candidate in k positions) instead of testing every position (Profile.cpp:1560-1570 tests them one by one).
+    The table is the exact integer recurrence of DESIGN.md section 4, it stays within k * 2^-64 of (1 - p)^k, and
+    reads sampled with it carry indels at the profile's rates, uniformly over the template."""
+    from fractions import Fraction
+    path = os.path.join(ROOT, "tests", "golden", "testData", prof).encode()
+    h = oracle_lib.orc_profile_load(path, 1, 350)
+    try:
+        L = oracle_lib.orc_profile_info(h, 3)
+        ab = (C.c_uint64 * 2)()
+        gaps = (C.c_uint64 * L)()
+        assert oracle_lib.orc_profile_indel_gaps(h, ab, gaps, L) == L
+        A, B = int(ab[0]), int(ab[1])
+        ins, dele = oracle_lib.orc_profile_rate(h, 0), oracle_lib.orc_profile_rate(h, 1)
+        # A / 2^64 = P(insertion test passes), (B - A) / 2^64 = P(it fails and the deletion test passes): the reference's
+        # two 32-bit tests `p <= insertRate`, `p < delRate / (1 - insertRate)`
+        c_i = A >> 32
+        assert A == c_i << 32 and abs(c_i / 2.0 ** 32 - ins) < 2.0 ** -31
+        c_d = (B - A) // ((1 << 32) - c_i)
+        assert B == A + ((1 << 32) - c_i) * c_d and abs(c_d / 2.0 ** 32 - dele / (1 - ins)) < 2.0 ** -31
+        q = (1 << 64) - B
+        want = q
+        for k in range(1, L + 1):
+            assert int(gaps[k - 1]) == want, k                        # the recurrence, exactly
+            exact = Fraction(q, 1 << 64) ** k
+            assert abs(Fraction(want, 1 << 64) - exact) < Fraction(k, 1 << 64)
+            want = (want * q) >> 64
+        # sampled reads: template of L 'A's; an insertion lengthens the read, a deletion shortens it
+        n_reads, longer, shorter = 60000, 0, 0
+        out_b, out_q = C.create_string_buffer(4 * L + 64), C.create_string_buffer(4 * L + 64)
+        for slot in range(n_reads):
+            np_ = oracle_lib.orc_predict_philox(h, b"A" * L, L, 1, 12345, 3, slot, out_b, out_q)
+            longer += np_ > L
+            shorter += np_ < L
+        # per read: P(at least one insertion with length > 0) etc.; compare with the per-position rates (events of
+        # length 0 and reads with both kinds blur it by a few percent of the rate; the bound is 5 sigma + 5 %)
+        for seen, rate in ((longer, A / 2.0 ** 64), (shorter, (B - A) / 2.0 ** 64)):
+            expect = n_reads * (1 - (1 - rate) ** L)
+            assert abs(seen - expect) < 5 * expect ** 0.5 + 0.08 * expect, (seen, expect)
+    finally:
+        oracle_lib.orc_profile_free(h)
