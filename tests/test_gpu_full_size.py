@@ -127,3 +127,43 @@ def test_named_configs_at_their_own_coverage(name, oracle_lib, tmp_path):
             whole = _record_digest([os.path.join(one, f)])
             sharded = _record_digest([os.path.join(parts, f"{f}.part{r}") for r in range(8)])
             assert whole == sharded and whole[0] > 2_000_000, f
+
+
+def test_bgzf_of_mates_larger_than_4_GiB(tmp_path):
+    """The block-gzip sink at production size: C2 at 64x, each mate > 4 GiB of text and > 140 k members; the whole
+    compressed stream of both mates, piped through `gzip -dc`, is exactly the text the context holds."""
+    import threading
+    cfg = _c2_config(str(tmp_path), 64)
+    sess = simuscop_amd.Session(cfg, device=0, write_files=0, quiet=1, seed=99)
+    try:
+        sess.weighted_length()
+        sess.set_reads(sess.planned_reads)
+        assert sess.prepare_batch(0)
+        sess.sample()
+        b1, b2, nf = sess.result()
+        assert b1 > (1 << 32) and b2 > (1 << 32)
+        want = sess.output_md5()
+        g = sess.compress()
+        for mate, total, gz in ((0, b1, g[0]), (1, b2, g[1])):
+            assert total / gz > 3.2
+            p = subprocess.Popen(["gzip", "-dc"], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+            got = {}
+
+            def digest():
+                h, n = hashlib.md5(), 0
+                for blk in iter(lambda: p.stdout.read(1 << 24), b""):
+                    h.update(blk)
+                    n += len(blk)
+                got["md5"], got["bytes"] = h.hexdigest(), n
+
+            t = threading.Thread(target=digest)
+            t.start()
+            for off in range(0, gz, 1 << 27):
+                p.stdin.write(sess.fetch_compressed(mate, min(1 << 27, gz - off), off))
+                print(f"mate {mate}: {off >> 20} MiB of {gz >> 20} piped", flush=True)   # (a long quiet run is taken for a hang)
+            p.stdin.close()
+            t.join()
+            assert p.wait() == 0
+            assert got == {"md5": want[mate], "bytes": total}
+    finally:
+        sess.close()
