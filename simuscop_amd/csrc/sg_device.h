@@ -17,11 +17,13 @@ constexpr size_t kTotalsBytes = kTotalsSegBase + 2 * 16 * 8 + 64;
 enum : uint32_t { KIND_HAP = 1, KIND_GC = 2, KIND_PLAN = 3, KIND_INDEL = 4, KIND_AUX = 5, KIND_BASE = 6 };
 
 // One planned fragment (16 B).  Written by plan_kernel, read by the indel and emit kernels.
-struct PairRec {
+struct PairRec {   // 32 bytes per planned fragment: everything indel_kernel needs of the fragment's window but its name base
   uint32_t win;     // window index in the batch
-  uint32_t relpos;  // pos - window.spos
+  uint32_t namepos; // fragment start inside its segment: (window.spos + draw) % segment size (Segment.cpp:780)
   uint32_t fl;      // bits 0..30 fragment length after chain-end clipping (0 = slot unused), bit 31 = SE reverse strand
   uint32_t k;       // ordinal of the fragment inside its window
+  uint64_t foff;    // offset of the fragment's first base in the chains buffer
+  uint64_t pad;
 };
 
 // Sequencing-indel event (Profile::getIndelSeq outcome): j | len<<16 | del<<31

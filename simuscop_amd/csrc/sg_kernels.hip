@@ -79,7 +79,8 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 #define PLAN_S 8
 
 __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch& B, const sg_window& win, uint64_t w,
-                                             uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r, const uint32_t* isz_row) {
+                                             uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r, const uint32_t* isz_row,
+                                             uint32_t seg_size, uint64_t chain_off) {
   uint32_t x[4];
   philox4x32_10((uint32_t)w + B.win_offset, attempt, 0, c3, B.k0, B.k1, x);
   // threadPool->randomInteger(spos, epos+1): (long)(start + (end-start)*(x/2^32)) in fp64
@@ -92,7 +93,10 @@ __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch
   const uint64_t avail = clen - (win.hap_base + pos);
   const uint32_t flen = avail < (uint64_t)isz ? (uint32_t)avail : isz;
   const uint32_t strand = B.paired ? 0u : (x[2] >> 31);  // randomInteger(0,2)
-  r.win = (uint32_t)w; r.relpos = pos - win.spos; r.fl = flen | (strand << 31);
+  r.win = (uint32_t)w; r.fl = flen | (strand << 31);
+  r.namepos = pos % seg_size;
+  r.foff = chain_off + win.hap_base + pos;
+  r.pad = 0;
   return flen >= (uint32_t)P.L;
 }
 
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   const int n = win.n_reads;
   const uint32_t planned = n <= 0 ? 0u : (B.paired ? ((uint32_t)n + 1u) / 2u : (uint32_t)n);
   const uint64_t clen = B.chain_len[win.chain];
+  const uint32_t seg_size = B.seg_size[win.seg];
+  const uint64_t chain_off = B.chain_off[win.chain];
   const uint32_t c3 = dev_ctx(KIND_PLAN, 0, B.batch_id);
   // can any attempt of this window fail?
   const uint64_t last_start = win.hap_base + win.spos + win.len - 1u;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   if (safe) {
     for (uint32_t k = j; k < planned; k += PLAN_S) {
       PairRec r;
-      plan_attempt(P, B, win, w, k, clen, c3, r, isz_row);
+      plan_attempt(P, B, win, w, k, clen, c3, r, isz_row, seg_size, chain_off);
       r.k = k;
       B.pairs[win.slot_base + k] = r;
     }
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   uint32_t done = 0, fail = 0, attempt = 0;
   while (done < planned) {
     PairRec r;
-    if (!plan_attempt(P, B, win, w, attempt++, clen, c3, r, isz_row)) {
+    if (!plan_attempt(P, B, win, w, attempt++, clen, c3, r, isz_row, seg_size, chain_off)) {
       if (++fail > 1000) break;
       continue;
     }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void plan_kernel(DevProfile P, DevBatch B) {
   }
   for (uint32_t k = done; k < planned; k++) {
     PairRec r;
-    r.win = (uint32_t)w; r.relpos = 0; r.fl = 0; r.k = k;
+    r.win = (uint32_t)w; r.namepos = 0; r.fl = 0; r.k = k; r.foff = 0; r.pad = 0;
     B.pairs[win.slot_base + k] = r;
   }
   B.win_actual[w] = done;
@@ -271,17 +277,15 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   // (slot, e, 0) of the read's e-th candidate: x = words (1, 0) against the table P(no candidate in k positions),
   // y = words (3, 2): an insertion iff floor(y evB / 2^64) < evA.  A read without indels (84 % at XTen rates) costs ONE
   // call and ONE compare (x < gap[L]); testing every position took 19 calls per 151-base read.
-  // What the read's row needs from its window, fetched BEFORE the candidate loop: three dependent gathers (window ->
-  // segment size, name base, chain offset -> bad-block bits) whose latency the loop's Philox calls then cover.
+  // What the read's row needs beyond its PairRec (plan_kernel put the window's part there), fetched BEFORE the candidate
+  // loop: the window's name base and the bad-block bits, two gathers whose latency the loop's Philox calls then cover.
   uint32_t namepos = 0, fragcount = 0, touches_bad = 0;
   uint64_t foff = 0;
   const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
   if (live) {
-    const sg_window win = B.windows[rec.win];
-    const uint32_t pos = win.spos + rec.relpos;
-    namepos = pos % B.seg_size[win.seg];
+    namepos = rec.namepos;
     fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-    foff = B.chain_off[win.chain] + win.hap_base + pos;
+    foff = rec.foff;
     // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
     // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
     // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
