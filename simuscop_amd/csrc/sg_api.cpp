@@ -179,7 +179,7 @@ static int finish_plan(sg_ctx* ctx, uint64_t nw, uint32_t n_segs, uint32_t n_slo
   SG_ENSURE(ctx->win_namebase, (nw + 1) * 4);
   SG_ENSURE(ctx->events, ((size_t)nm * n_slots + 1) * 4 * SG_MAX_EVENTS);
   SG_ENSURE(ctx->recoff, ((size_t)nm * n_slots + 1) * 4);
-  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 64);
+  SG_ENSURE(ctx->meta, ((size_t)nm * n_slots + 1) * 48);
   SG_ENSURE(ctx->totals, sg::kTotalsBytes);
   SG_ENSURE(ctx->bsum, ((size_t)nm * ((n_slots + 255) / 256) + 1) * 8);
   SG_HIP(hipMemcpyAsync(ctx->prefix.p, name_prefix, plen, hipMemcpyHostToDevice, ctx->stream));

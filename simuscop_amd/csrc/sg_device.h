@@ -91,7 +91,7 @@ struct DevBatch {
   uint64_t* blkbase;            // [2][ceil(n_slots / 256)] offset of a block's first record inside its segment of 2^seg_shift blocks
                                 // (sums by indel_kernel, scanned in place by block_base_kernel; the segments' own bases: totals + kTotalsSegBase)
   uint32_t seg_shift;
-  uint4* meta;                  // [2][n_slots][4] per-read 64-byte rows for the emit kernel: m0, m1, header text (32 B)
+  uint4* meta;                  // [2][n_slots][3] per-read 48-byte rows for the emit kernels: m0, m1, name text (indel_kernel)
   // (from byte 128 on: the emit kernels' read-group counters, one 128-byte line each, see GroupRuns in sg_kernels.hip)
   uint64_t* totals;             // [0],[1] bytes per mate; [2] fragments produced; [3] flags (1 events, 2 slow queue full); [4] slow-queue counts;
   uint2* slowq;                 // [2][slowq_cap] (slot, item) left to emit_slow_kernel by the fast emit kernel

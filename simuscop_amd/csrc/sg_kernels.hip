@@ -201,23 +201,23 @@ __device__ __forceinline__ uint64_t rec_offset(const DevBatch& B, uint32_t m, ui
 // indel pass: one lane per read
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
-  // The reads' 64-byte rows leave through LDS: written by their lanes (16 bytes and single words at a stride of 64
-  // bytes: straight to memory every store instruction touched 64 cache lines), stored by the wave as 4 KB in one piece.
-  __shared__ uint4 row_lds[256 * 4];
+  // The reads' 48-byte rows leave through LDS: written by their lanes (16 bytes and single characters at a stride of 48:
+  // straight to memory every store instruction touched 64 cache lines), stored by the wave as 3 KB in one piece.
+  __shared__ uint4 row_lds[256 * 3];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
   const uint32_t lane = threadIdx.x & 63u;
-  uint4* const wave_rows = row_lds + (threadIdx.x & ~63u) * 4u;
-  uint4* const my_row = wave_rows + lane * 4u;
+  uint4* const wave_rows = row_lds + (threadIdx.x & ~63u) * 3u;
+  uint4* const my_row = wave_rows + lane * 3u;
   const uint32_t t_wave = t - lane;  // the wave's first slot
   auto store_rows = [&]() {
     wave_lds_sync();
-    uint4* dst = B.meta + ((size_t)m * B.n_slots + t_wave) * 4;
-    const uint32_t n_rows = B.n_slots - t_wave;  // rows of the wave that exist (>= 1: lane 0 is inside the batch)
+    uint4* dst = B.meta + ((size_t)m * B.n_slots + t_wave) * 3;
+    const uint32_t n_pieces = min(B.n_slots - t_wave, 64u) * 3u;  // 16-byte pieces of the wave's rows that exist
 #pragma unroll
-    for (uint32_t i = 0; i < 4u; i++) {
-      const uint32_t q = i * 64u + lane;  // 16-byte piece of the wave's block: row q / 4
-      if ((q >> 2) < n_rows) dst[q] = wave_rows[q];
+    for (uint32_t i = 0; i < 3u; i++) {
+      const uint32_t q = i * 64u + lane;
+      if (q < n_pieces) dst[q] = wave_rows[q];
     }
   };
   // the table of the indel distances (see below), staged by the whole block before any wave can leave
@@ -257,14 +257,12 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     if (threadIdx.x == 0) B.blkbase[(size_t)m * gridDim.x + blockIdx.x] = all;
   };
   if (__ballot(flen != 0u) == 0ull) {  // nothing planned in the whole wave
-    my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
+    my_row[0] = my_row[1] = my_row[2] = make_uint4(0, 0, 0, 0);
     if (t_wave < B.n_slots) store_rows();
     block_prefix();
     return;
   }
-  if (!flen) {
-    my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
-  }
+  if (!flen) my_row[0] = my_row[1] = my_row[2] = make_uint4(0, 0, 0, 0);
   // (lanes without a fragment stay in the kernel for the wave-wide steps below, doing nothing in between)
   const bool live = flen != 0u;
   const int L = live ? P.L : 0;
@@ -336,26 +334,21 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
     const uint32_t np = (uint32_t)(L + dl);
     const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
     rl = hdr + 2u * np + 4u;
-    // Per-read 64-byte row for the emit kernel: m0 = fragment offset + name fields, m1 = lengths,
-    // then the header text "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824) when it fits
-    // 32 bytes; the read's first item lane stores it in front of the bases (emit_fast_kernel).
+    // Per-read 48-byte row for the emit kernels: m0 = fragment offset + the two numbers of the read's name
+    // "@popu#chr#pos%segsize#fragCount[/m]" (Segment.cpp:780,809,824), m1 = lengths, reciprocal, event, then the
+    // name's own part "pos#count[/m]\n" as text when it fits 16 bytes (emit_fast_kernel stores it behind the batch's
+    // constant prefix; this kernel has the VALU time for the digits, that one has not).
     my_row[0] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
     // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
     // (sg_load_profile rejects profiles that could violate the bound)
     // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
     my_row[1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
                                      nev == 1u ? first_ev : 0u);
-    if (hdr <= 32u) {
-      // text straight into the row's last 32 bytes (LDS): the prefix as words, then single characters -- the digits of a
-      // number from its last one backwards
+    my_row[2] = make_uint4(0, 0, 0, 0);
+    if (hdr - B.prefix_len <= 16u) {
       uint8_t* hb = (uint8_t*)(my_row + 2);
-      if (B.prefix_len <= 16u) {
-        my_row[2] = make_uint4(B.prefix_w[0], B.prefix_w[1], B.prefix_w[2], B.prefix_w[3]);
-      } else {
-        for (uint32_t i = 0; i < B.prefix_len; i++) hb[i] = B.prefix[i];  // (B.prefix_w holds 16 bytes)
-      }
-      uint32_t o = B.prefix_len;
-      auto put_dec = [&](uint32_t v) {
+      uint32_t o = 0;
+      auto put_dec = [&](uint32_t v) {  // the digits of a number from its last one backwards
         const uint32_t nd = ndigits(v);
         for (uint32_t k = nd; k-- > 0u;) {
           const uint32_t qd = v / 10u;
@@ -376,54 +369,51 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// header (fallback): one lane per read, after the offset scan.  The fast emit kernel stores header
-// texts of <= 32 bytes itself (from the read's row); this kernel serves the generic emit kernel and
-// over-long headers.
+// Read names "@popu#chr#pos%segsize#fragCount[/m]\n" (Segment.cpp:780,809,824).  emit_fast_kernel stores the names of
+// its reads itself (phase 0: the batch's prefix from the kernel arguments + the read's part from its row) when the
+// prefix fits 16 bytes; header_kernel (one lane per read, after the offset scan) serves the generic emit kernel and
+// longer prefixes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void header_kernel(DevBatch B, uint32_t only_long) {
+// any name, byte stream -> unaligned dword stores (7 instead of 27 byte stores per record)
+__device__ __attribute__((noinline)) void write_name(uint8_t* hp, const uint8_t* __restrict__ prefix, uint32_t prefix_len,
+                                                     uint32_t namepos, uint32_t fragcount, uint32_t paired, uint32_t m) {
+  uint32_t w = 0, nb = 0;
+  auto push = [&](uint32_t b) {
+    w |= b << (nb * 8u);
+    if (++nb == 4u) { __builtin_memcpy(hp, &w, 4); hp += 4; w = 0; nb = 0; }
+  };
+  auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
+    const uint32_t nd = ndigits(v);
+    uint64_t lo = 0;  // last (up to 8) digits, most significant in byte 0
+    uint32_t hi = 0;  // leading digits of 9- and 10-digit numbers
+    for (uint32_t k = 0; k < nd; k++) {
+      const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
+      if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
+      v = qd;
+    }
+    for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
+    for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
+  };
+  for (uint32_t i = 0; i < prefix_len; i++) push(prefix[i]);
+  push_dec(namepos);
+  push('#');
+  push_dec(fragcount);
+  if (paired) { push('/'); push('1' + m); }
+  push('\n');
+  for (uint32_t i = 0; i < nb; i++) hp[i] = (uint8_t)(w >> (8u * i));
+}
+
+__global__ __launch_bounds__(256) void header_kernel(DevBatch B) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
   if (t >= B.n_slots) return;
   const size_t idx = (size_t)m * B.n_slots + t;
-  const uint4 m1 = B.meta[idx * 4 + 1];
+  const uint4 m1 = B.meta[idx * 3 + 1];
   if (!(m1.x & 0x7FFFFFFFu)) return;
-  if (only_long && (m1.y >> 22) <= 32u) return;  // written by the emit kernel from the row
-  const uint4 m0 = B.meta[idx * 4];
+  const uint4 m0 = B.meta[idx * 3];
   const uint64_t ooff = rec_offset(B, m, t);
   if (ooff + ((m1.y >> 22) + 2u * (m1.y & 0xFFFFu) + 4u) > B.out_cap[m]) return;  // (the record's length: header + 2 lines + 4 line breaks and '+')
-  const uint32_t namepos = m0.z, fragcount = m0.w;
-  if (!(B.diag & 4u)) {
-    // byte stream -> unaligned dword stores (7 instead of 27 byte stores per record)
-    uint8_t* hp = B.out[m] + ooff;
-    uint32_t w = 0, nb = 0;
-    auto push = [&](uint32_t b) {
-      w |= b << (nb * 8u);
-      if (++nb == 4u) { __builtin_memcpy(hp, &w, 4); hp += 4; w = 0; nb = 0; }
-    };
-    auto push_dec = [&](uint32_t v) {  // digits generated least-significant first into a byte queue
-      const uint32_t nd = ndigits(v);
-      uint64_t lo = 0;  // last (up to 8) digits, most significant in byte 0
-      uint32_t hi = 0;  // leading digits of 9- and 10-digit numbers
-      for (uint32_t k = 0; k < nd; k++) {
-        const uint32_t qd = v / 10u, d = '0' + (v - qd * 10u);
-        if (k < 8u) lo = (lo << 8) | d; else hi = (hi << 8) | d;
-        v = qd;
-      }
-      for (uint32_t k = 8; k < nd; k++) { push(hi & 0xFFu); hi >>= 8; }
-      for (uint32_t k = 0; k < (nd < 8u ? nd : 8u); k++) { push((uint32_t)lo & 0xFFu); lo >>= 8; }
-    };
-    if (B.prefix_len <= 16u) {
-      for (uint32_t i = 0; i < B.prefix_len; i++) push((B.prefix_w[i >> 2] >> (8u * (i & 3u))) & 0xFFu);
-    } else {
-      for (uint32_t i = 0; i < B.prefix_len; i++) push(B.prefix[i]);
-    }
-    push_dec(namepos);
-    push('#');
-    push_dec(fragcount);
-    if (B.paired) { push('/'); push('1' + m); }
-    push('\n');
-    for (uint32_t i = 0; i < nb; i++) hp[i] = (uint8_t)(w >> (8u * i));
-  }
+  if (!(B.diag & 4u)) write_name(B.out[m] + ooff, B.prefix, B.prefix_len, m0.z, m0.w, B.paired, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,8 +870,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
     uint4 my0 = make_uint4(0, 0, 0, 0), my1 = make_uint4(0, 0, 0, 0);
     if (lane < G && t < B.n_slots) {
       const size_t idx = (size_t)m * B.n_slots + t;
-      my0 = B.meta[idx * 4];
-      my1 = B.meta[idx * 4 + 1];
+      my0 = B.meta[idx * 3];
+      my1 = B.meta[idx * 3 + 1];
       const uint64_t ooff = rec_offset(B, m, t);
       my0.z = (uint32_t)ooff;
       my0.w = (uint32_t)(ooff >> 32);
@@ -1236,10 +1226,29 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     uint64_t ooff = 0;
     if (lane < G && t < B.n_slots) {
       const size_t idx = (size_t)m * B.n_slots + t;
-      my0 = B.meta[idx * 4];
-      my1 = B.meta[idx * 4 + 1];
+      my0 = B.meta[idx * 3];
+      my1 = B.meta[idx * 3 + 1];
       ooff = rec_offset(B, m, t);
-      if (my1.x & 0x7FFFFFFFu) items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
+      if (my1.x & 0x7FFFFFFFu) {
+        items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
+        // The read's name, stored in front of where the step loop will put the bases: the batch's prefix, then the
+        // read's own part from its row (indel_kernel made the text), two pieces of <= 16 bytes.
+        if (B.prefix_len <= 16u && !(B.diag & 2u)) {
+          uint8_t* rec = B.out[m] + ooff;
+          const uint32_t nv = (my1.y >> 22) - B.prefix_len;
+          if (__builtin_expect(nv > 16u, 0)) {
+            write_name(rec, B.prefix, B.prefix_len, my0.z, my0.w, PAIRED ? 1u : 0u, m);
+          } else {
+            const uint64_t p_lo = ((uint64_t)B.prefix_w[1] << 32) | B.prefix_w[0], p_hi = ((uint64_t)B.prefix_w[3] << 32) | B.prefix_w[2];
+            if (B.prefix_len == 16u) { __builtin_memcpy(rec, &p_lo, 8); __builtin_memcpy(rec + 8, &p_hi, 8); }
+            else store_var(rec, p_lo, p_hi, B.prefix_len);
+            const uint4 tx = B.meta[idx * 3 + 2];
+            uint8_t* q = rec + B.prefix_len;
+            if (nv == 16u) __builtin_memcpy(q, &tx, 16);
+            else store_var(q, ((uint64_t)tx.y << 32) | tx.x, ((uint64_t)tx.w << 32) | tx.z, nv);
+          }
+        }
+      }
     }
     // The group's text is one contiguous range starting at its first record: a buffer descriptor on that address, the
     // records at 32-bit offsets from it (row word 2).  Offsets past 2^31 are the "no store" value of idle lanes.
@@ -1495,16 +1504,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       if (r1.x & 0x7FFFFFFFu) {
         const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
         uint8_t* rec = gout + r0.z;
-        if (hl <= 32u) {
-          const uint4* hrow = B.meta + ((size_t)m * B.n_slots + t) * 4 + 2;
-          const uint4 h0 = hrow[0], h1 = hrow[1];
-          uint8_t* q = rec;
-          uint32_t rem = hl;
-          uint4 part = h0;
-          if (hl >= 16u) { __builtin_memcpy(q, &h0, 16); q += 16; rem -= 16u; part = h1; }
-          if (rem == 16u) __builtin_memcpy(q, &part, 16);
-          else store_var(q, ((uint64_t)part.y << 32) | part.x, ((uint64_t)part.w << 32) | part.z, rem);
-        }
         const uint4 tr = make_uint4(r0.x, r0.y, r1.z, r1.w);  // the parked last item (fast_item)
         if ((np & 7u) == 7u && tr.x != 0xFFFFFFFFu) {
           // the last item went out with the steps, line breaks and the "+" line included
@@ -1546,8 +1545,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, D
     const bool act = i < n;
     const uint2 e = q[act ? i : b0];
     const size_t idx = (size_t)m * B.n_slots + e.x;
-    uint4 m0 = B.meta[idx * 4];
-    const uint4 m1 = B.meta[idx * 4 + 1];
+    uint4 m0 = B.meta[idx * 3];
+    const uint4 m1 = B.meta[idx * 3 + 1];
     const uint64_t ooff = rec_offset(B, m, e.x);
     m0.z = (uint32_t)ooff;
     m0.w = (uint32_t)(ooff >> 32);
@@ -1778,10 +1777,9 @@ bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
   const bool fast = emit_uses_fast_kernel(P, B);
-  // fast kernel: headers <= 32 bytes come from the rows; 24 bytes beyond the prefix is the longest tail
-  if (fast && B.prefix_len + 24u <= 32u) return;
+  if (fast && B.prefix_len <= 16u) return;  // the straight-line kernel writes the names of its reads itself
   dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
-  hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B, fast ? 1u : 0u);
+  hipLaunchKernelGGL(header_kernel, grid, dim3(256), 0, s, B);
 }
 uint32_t scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 uint32_t record_seg_shift(uint32_t n_slots) {  // smallest shift with at most 16 segments of 2^shift blocks of 256 reads
