@@ -9,9 +9,11 @@
 //   plan_kernel      Segment::yieldReads draw loop   (lib/segment/Segment.cpp:735-762, 848)
 //   namebase_kernel  per-segment fragCount numbering (Segment.cpp:732,763)
 //   indel_kernel     Profile::predict indel pass     (lib/profile/Profile.cpp:1607-1634, 1556-1574)
-//   scan_*           record offsets (replaces the 50 MB per-worker buffers + SeqWriter mutex,
-//                    Segment.cpp:695-707,834-846; lib/seqwriter/SeqWriter.cpp:49-54)
-//   emit_kernel      Profile::predict sampling loop  (Profile.cpp:1636-1700) + FASTQ formatting
+//   block_base_kernel  record offsets: in-block prefix by indel_kernel, block and segment bases here (replaces the
+//                    50 MB per-worker buffers + SeqWriter mutex, Segment.cpp:695-707,834-846;
+//                    lib/seqwriter/SeqWriter.cpp:49-54)
+//   emit_fast_kernel, emit_slow_kernel, emit_kernel (generic) + header_kernel
+//                    Profile::predict sampling loop  (Profile.cpp:1636-1700) + FASTQ formatting
 //                    (Segment.cpp:803-832)
 //   gc_kernel        calculateGCPercent              (lib/mydefine/MyDefine.cpp:279-303)
 #include <algorithm>
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
   uint32_t rl = 0;  // the read's record length (0: nothing planned)
   // Record offsets: exclusive prefix of the record lengths inside the block of 256 reads, here; the blocks' bases by
-  // one small kernel afterwards (scan_sums_kernel).  offset = base[block] + prefix (rec_offset()).
+  // one small kernel afterwards (block_base_kernel).  offset = base[block] + prefix (rec_offset()).
   __shared__ uint32_t wave_len[4];
   auto block_prefix = [&]() {
     uint32_t incl = rl;
@@ -936,8 +938,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
 //   * table addresses come from a per-item look-up row (bin offsets of the item's eight positions; the short
 //     contexts of a read's first two bases are table regions of their own, selected by that row);
 //   * a group's reads walk the steps as one item stream, 64 items per step, ordered by event class;
-//   * what is per read rather than per item -- header text, the partial last item, "\n+\n" and '\n' --
-//     is stored by a per-read pass once per group (the last item waits in the read's own LDS row);
+//   * what is per read rather than per item: the name goes out at phase 0 (lane = read; prefix from the kernel
+//     arguments, the read's own part from its row), the partial last item, "\n+\n" and '\n' are stored by a per-read
+//     pass once per group (the last item waits in the read's own LDS row);
 //   * windows holding a non-ACGT base and items two sequencing indels reach into (both rare) go to a global
 //     queue for emit_slow_kernel.
 // ------------------------------------------------------------------------------------------------
@@ -1494,7 +1497,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     }
     if (nslow) flush_slow();
     if (nfix) flush_fix();
-    // ---- per-read pass, lane = read: header text, last partial item, record separators ----
+    // ---- per-read pass, lane = read: last partial item, record separators ----
     // These byte-granular stores touch lines the steps above have just written from this wave, so
     // they merge in L2.  Reads whose last item went to the generic code (0xFFFFFFFF row) get only the
     // separators here; emit_slow_kernel writes the same separator bytes again (benign).
