@@ -1681,14 +1681,26 @@ __global__ __launch_bounds__(256) void tile_kernel(const sg_window_gen* __restri
   seg_ord[w] = G.seg;
   win_ord[w] = (uint32_t)(w - seg_first[G.seg]);
 }
-// lane = segment: weight sum in window order (the reference's summation order, Segment.cpp:627-630)
-__global__ __launch_bounds__(64) void seg_sum_kernel(const double* __restrict__ wt, const uint64_t* __restrict__ seg_first, uint32_t n_segs,
-                                                     double* __restrict__ out) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_segs) return;
+// workgroup = segment: weight sum in window order (the reference's summation order, Segment.cpp:627-630; fp64 addition
+// does not reassociate).  The whole workgroup stages tiles of the weights in LDS (coalesced), its first lane adds them
+// one after the other: the chain of dependent adds is all that is serial (one lane per segment reading its weights
+// from memory itself took 0.27 ms for 65 segments of 2000 windows).
+#define SEG_SUM_TILE 4096
+__global__ __launch_bounds__(256) void seg_sum_kernel(const double* __restrict__ wt, const uint64_t* __restrict__ seg_first, uint32_t n_segs,
+                                                      double* __restrict__ out) {
+  __shared__ double tile[SEG_SUM_TILE];
+  const uint32_t k = blockIdx.x;
+  const uint64_t w0 = seg_first[k], w1 = seg_first[k + 1];
   double acc = 0.0;
-  for (uint64_t w = seg_first[k]; w < seg_first[k + 1]; w++) acc = __dadd_rn(acc, wt[w]);
-  out[k] = acc;
+  for (uint64_t base = w0; base < w1; base += SEG_SUM_TILE) {
+    const uint32_t n = (uint32_t)(w1 - base < SEG_SUM_TILE ? w1 - base : SEG_SUM_TILE);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tile[i] = wt[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0u)
+      for (uint32_t i = 0; i < n; i++) acc = __dadd_rn(acc, tile[i]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0u) out[k] = acc;
 }
 // lane = window of an active segment: fragRCs[i] = (long)(fragWeights[i] * readCount / totalWL), Segment.cpp:466-470
 __global__ __launch_bounds__(256) void window_reads_kernel(const sg_window_gen* __restrict__ gens, const uint64_t* __restrict__ prefix,
@@ -1696,23 +1708,38 @@ __global__ __launch_bounds__(256) void window_reads_kernel(const sg_window_gen* 
                                                            const sg_active_seg* __restrict__ act, sg_window* __restrict__ rows,
                                                            unsigned long long* __restrict__ seg_sum) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n) return;
-  const uint32_t g = gen_of(prefix, n_gens, w);
-  const sg_window_gen G = gens[g];
-  const uint64_t t = w - prefix[g], off = t * frag;
-  const sg_active_seg A = act[G.seg];
-  const double total = __dadd_rn(A.weight, 2.2204e-16);
-  const long long rc = (long long)__ddiv_rn(__dmul_rn(wt[G.first_window + t], (double)A.reads), total);
-  sg_window o;
-  o.hap_base = G.hap_base;
-  o.chain = G.chain;
-  o.spos = (uint32_t)off;
-  o.len = (uint32_t)(G.hap_len - off < frag ? G.hap_len - off : frag);
-  o.n_reads = (int32_t)rc;
-  o.seg = G.seg;
-  o.slot_base = 0;
-  rows[w] = o;
-  atomicAdd(seg_sum + G.seg, (unsigned long long)rc);
+  const bool valid = w < n;
+  uint32_t seg = 0xFFFFFFFFu;
+  long long rc = 0;
+  if (valid) {
+    const uint32_t g = gen_of(prefix, n_gens, w);
+    const sg_window_gen G = gens[g];
+    const uint64_t t = w - prefix[g], off = t * frag;
+    const sg_active_seg A = act[G.seg];
+    const double total = __dadd_rn(A.weight, 2.2204e-16);
+    rc = (long long)__ddiv_rn(__dmul_rn(wt[G.first_window + t], (double)A.reads), total);
+    sg_window o;
+    o.hap_base = G.hap_base;
+    o.chain = G.chain;
+    o.spos = (uint32_t)off;
+    o.len = (uint32_t)(G.hap_len - off < frag ? G.hap_len - off : frag);
+    o.n_reads = (int32_t)rc;
+    o.seg = G.seg;
+    o.slot_base = 0;
+    rows[w] = o;
+    seg = G.seg;
+  }
+  // The segment's sum (an integer: any order): a wave's windows are nearly always of ONE segment -- one atomic for the
+  // wave then, not 64 on the same address (64 k single-address atomics were 0.37 ms of this kernel's 0.38).
+  const uint32_t seg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg);  // (the first lane of a wave that has one is valid)
+  if (__ballot(valid && seg != seg0) == 0ull) {
+    unsigned long long sum = (unsigned long long)rc;  // 0 on the lanes past n
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((threadIdx.x & 63u) == 0u && valid) atomicAdd(seg_sum + seg0, sum);
+  } else if (valid) {
+    atomicAdd(seg_sum + seg, (unsigned long long)rc);
+  }
 }
 // lane = active segment: the remainder goes to the segment's first window (Segment.cpp:472-474)
 __global__ __launch_bounds__(64) void seg_remainder_kernel(const sg_active_seg* __restrict__ act, const uint32_t* __restrict__ seg_first,
@@ -1912,7 +1939,7 @@ void launch_tile(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_g
   if (n) hipLaunchKernelGGL(tile_kernel, dim3(blocks256(n)), dim3(256), 0, s, gens, prefix, n_gens, n, frag, seg_first, out, seg_ord, win_ord);
 }
 void launch_seg_sum(const double* wt, const uint64_t* seg_first, uint32_t n_segs, double* out, hipStream_t s) {
-  if (n_segs) hipLaunchKernelGGL(seg_sum_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, s, wt, seg_first, n_segs, out);
+  if (n_segs) hipLaunchKernelGGL(seg_sum_kernel, dim3(n_segs), dim3(256), 0, s, wt, seg_first, n_segs, out);
 }
 void launch_window_reads(const sg_window_gen* gens, const uint64_t* prefix, uint32_t n_gens, uint64_t n, uint32_t frag, const double* wt,
                          const sg_active_seg* act, const uint32_t* seg_first, uint32_t n_act, sg_window* rows, unsigned long long* seg_sum,
