@@ -7,6 +7,14 @@ import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port():
+    """A port nobody listens on right now (a fixed one can still be held by the previous run's rendezvous)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
 WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
@@ -28,7 +36,7 @@ def test_balance_two_ranks(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
@@ -82,11 +90,13 @@ def test_ranks_owning_different_chromosomes_apportion_like_one_rank(tmp_path):
     script.write_text(OWNER_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
-    rows = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"rank"')), key=lambda d: d["rank"])
+    import re
+    # (the two ranks share the pipe: their lines can arrive glued together, so objects are cut out, not lines)
+    rows = sorted((json.loads(m) for m in re.findall(r'\{"rank".*?\}', r.stdout)), key=lambda d: d["rank"])
     assert len(rows) == 2 and all(d["rc"] == 0 for d in rows)
     from simuscop_amd import dist as sd, synth
     lens = synth.GRCH38_LENGTHS

@@ -15,6 +15,14 @@ SEED = (cases.FAKE_SEC << 32) | cases.FAKE_NSEC
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """A port nobody listens on right now (a fixed one can still be held by the previous run's rendezvous)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _run_gpu(cfg, out, extra=(), env=None):
     r = subprocess.run([SIMU, cfg, "--seed", str(SEED), "--out", out, "--quiet", "--stats", *extra],
                        capture_output=True, text=True, timeout=600, env=env)
@@ -109,7 +117,7 @@ def test_launcher_two_ranks_merge(tmp_path):
     _run_gpu(cfg, one)
     env = dict(os.environ, SIMUSCOP_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", "-m", "simuscop_amd.run", cfg,
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), "-m", "simuscop_amd.run", cfg,
                         "--seed", str(SEED), "--merge", "--backend", "gloo"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -162,7 +170,7 @@ def test_ranks_owning_whole_chromosomes(name, tmp_path):
     if name != "wgs_pe_variants":
         return
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29543", "-m", "simuscop_amd.run", cfg, "--seed", str(SEED), "--merge", "--backend", "gloo",
+                        "--master-port", _free_port(), "-m", "simuscop_amd.run", cfg, "--seed", str(SEED), "--merge", "--backend", "gloo",
                         "--shard-contigs"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out_dir = [l.split("=", 1)[1].strip() for l in open(cfg) if l.startswith("output")][0]
