@@ -17,6 +17,8 @@ per-chromosome GC-weighted lengths over RCCL, after which every rank derives its
 the reference apportions `reads*chrWL/WL`.  No data-path collective.
 `--workload c3` is strong scaling of ONE 24-contig genome in GRCh38 proportions (`--scale`), whole run
 including ingest: ranks own whole contigs balanced by length, ingest only those (simuReads --rank/--world).
+`--workload c4` is the same for the tumour mixture of BASELINE configs[4]: four populations with variants and SNPs, 60x
+(bench_c3.py).
 """
 from __future__ import annotations
 
@@ -182,10 +184,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
     ap.add_argument("--scale", type=float, default=1.0, help="c3: contig lengths = GRCh38 primary lengths x scale")
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
-    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--coverage", type=int, default=None, help="default: 30 (c2, c3), 60 (c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-pinned", action="store_true", help="skip the pinned-host legs (plain + gzip) after the timed region")
     ap.add_argument("--no-md5", action="store_true")
@@ -199,9 +201,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    if args.workload == "c3":
+    if args.workload in ("c3", "c4"):
         import bench_c3
         return bench_c3.main(args)
+    if args.coverage is None:
+        args.coverage = 30
 
     import torch
     import torch.distributed as dist

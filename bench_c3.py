@@ -7,6 +7,11 @@ sampling of every chromosome -- with the FASTQ text left in HBM.  With N ranks t
 (longest first by length, host/variants.cpp Genome::assign_contigs): a rank ingests, scans and samples only its own;
 the one exchange is the all-reduce of the per-chromosome GC-weighted lengths (RCCL; 24 doubles per population).
 value = pairs of the whole genome / slowest rank's wall time per step.
+
+`--workload c4` (BASELINE.json configs[4], SURVEY.md 8(d) "C4"): the same genome, four populations clone1, clone2, clone3,
+normal with the reference's testData/variations.txt pattern on every contig of the three clones, a SNP every ~2 kb,
+abundance 0.3 / 0.25 / 0.35 / 0.1, 60x: 96 (population, chromosome) batches, haplotypes with insertions, deletions, SNVs
+and copy-number changes assembled on the device.
 """
 from __future__ import annotations
 
@@ -35,6 +40,26 @@ def _genome(scale, rank, barrier):
         os.replace(path + ".fai.tmp", path + ".fai")
     barrier()
     return path, contigs
+
+
+def _tumour_files(scale, contigs, rank, barrier):
+    """Variation, SNP and abundance files of the C4 mixture (made once per box by rank 0)."""
+    from simuscop_amd import synth
+    base = f"/tmp/simuscop_c4_scale{scale:g}"
+    paths = {k: f"{base}_{k}.txt" for k in ("variation", "snp", "abundance")}
+    if rank == 0 and not all(os.path.exists(p) for p in paths.values()):
+        rows, snps = [], []
+        for i, (name, length) in enumerate(contigs):
+            key = name[3:] if name.startswith("chr") else name
+            for popu in ("clone1", "clone2", "clone3"):
+                rows += synth.variation_rows(popu, key, length / 63025520.0)
+            snps += synth.snp_rows(key, length, 1500, 100 + i)
+        for k, data in (("variation", rows), ("snp", snps), ("abundance", ["0.3\t0.25\t0.35\t0.1"])):
+            with open(paths[k] + ".tmp", "w") as f:
+                f.write("\n".join(data) + "\n")
+            os.replace(paths[k] + ".tmp", paths[k])
+    barrier()
+    return paths
 
 
 def main(args):
@@ -66,9 +91,17 @@ def main(args):
 
     fasta, contigs = _genome(args.scale, rank, barrier)
     prof_file, L = bench.PROFILES[args.profile]
-    cfg = f"/tmp/simuscop_c3_config_r{rank}.txt"
-    bench.write_config(cfg, fasta, f"/tmp/simuscop_c3_out_r{rank}", coverage=args.coverage, threads=min(64, os.cpu_count() or 1),
+    tumour = args.workload == "c4"
+    coverage = args.coverage if args.coverage is not None else (60 if tumour else 30)
+    cfg = f"/tmp/simuscop_{args.workload}_config_r{rank}.txt"
+    bench.write_config(cfg, fasta, f"/tmp/simuscop_{args.workload}_out_r{rank}", coverage=coverage, threads=min(64, os.cpu_count() or 1),
                        profile=prof_file)
+    if tumour:
+        extra = _tumour_files(args.scale, contigs, rank, barrier)
+        with open(cfg) as f:
+            text = f.read().replace("name = sim\n", "name = clone1, clone2, clone3, normal\n")
+        with open(cfg, "w") as f:
+            f.write(text + f"variation = {extra['variation']}\nsnp = {extra['snp']}\nabundance = {extra['abundance']}\n")
     opts = dict(device=local_rank, quiet=1, write_files=0, seed=0x5EED0C3, shard_rank=rank, shard_world=world)
     exchange = None
     if world > 1:
@@ -112,11 +145,13 @@ def main(args):
             "value": total_pairs / dt_max, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"C3: 24 contigs, GRCh38 primary lengths x {args.scale:g} ({sum(l for _, l in contigs)} bp), "
-                                   f"{prof_file[:-8]} profile ({L} bp), PE, {args.coverage}x, insertSize 350; whole simuReads run per step "
+            "config": {"workload": ("C4: four populations (variations + SNPs, abundance 0.3/0.25/0.35/0.1) of " if tumour else "C3: ") +
+                                   f"24 contigs, GRCh38 primary lengths x {args.scale:g} ({sum(l for _, l in contigs)} bp), "
+                                   f"{prof_file[:-8]} profile ({L} bp), PE, {coverage}x, insertSize 350; whole simuReads run per step "
                                    f"(ingest + haplotypes + GC scan + apportioning + sampling), text left in HBM",
                        "pairs_per_step": pairs_per_step,
-                       "parallelism": f"{world} rank(s), whole chromosomes per rank (longest first); all-reduce of 24 weighted lengths"},
+                       "parallelism": f"{world} rank(s), whole chromosomes per rank (longest first); all-reduce of 24 weighted lengths"
+                                      + (" per population" if tumour else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "kernel": "emit_fast_kernel", "kernel_ms": slow["kernel_ms"]["emit"],
                          "note": "kernel time summed over the chromosomes of the rank with the largest share (its last run)",

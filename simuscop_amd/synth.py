@@ -107,3 +107,47 @@ def write_fasta(path: str, contigs: Sequence[Tuple[str, int]], seed: int, line_l
 
 def grch38_contigs(scale: float = 1.0) -> list:
     return [(n, max(1000, int(l * scale))) for n, l in zip(GRCH38_NAMES, GRCH38_LENGTHS)]
+
+
+def variation_rows(popu: str, chr_name: str, scale: float) -> list:
+    """Rows of a variation file for one (population, chromosome): the pattern of the reference's
+    testData/variations.txt (insertions, deletions, SNVs, CNVs on a 63 Mbp chromosome) with the positions x scale."""
+    def P(x):
+        return max(1, int(x * scale))
+    rows = []
+    ins = [(4500100, "tcgagtcg", "homo"), (11000100, "tcgagtc", "homo"), (12000100, "tcgagt", "het"),
+           (44000100, "tcgagtcg", "het"), (57000100, "tcgagtc", "homo"), (61000100, "tcgagt", "het")]
+    dels = [(3000100, 10, "homo"), (5000100, 9, "het"), (9500100, 8, "homo"), (48000100, 8, "het"),
+            (58000100, 7, "homo"), (62000100, 6, "het")]
+    snvs = [(2000100, "a", "T", "homo"), (4000100, "T", "G", "homo"), (8500100, "A", "G", "het"),
+            (9000100, "G", "C", "homo"), (11500100, "G", "C", "homo"), (46000100, "c", "T", "het"),
+            (51000100, "g", "A", "het"), (53000100, "C", "G", "het"), (55000100, "C", "T", "homo"),
+            (56000100, "A", "T", "homo"), (59000100, "A", "T", "homo")]
+    cnvs = [(5000000, 6000000, 1, 1), (10000000, 14500000, 3, 2), (37500000, 40000000, 4, 3),
+            (40000000, 43500000, 1, 1), (44000000, 47000000, 2, 2), (49000000, 53000000, 1, 1)]
+    for p, s, t in ins:
+        rows.append(f"i\t{popu}\t{chr_name}\t{P(p)}\t{s}\t{t}")
+    for p, l, t in dels:
+        rows.append(f"d\t{popu}\t{chr_name}\t{P(p)}\t{l}\t{t}")
+    for p, r, a, t in snvs:
+        rows.append(f"s\t{popu}\t{chr_name}\t{P(p)}\t{r}\t{a}\t{t}")
+    for s, e, cn, m in cnvs:
+        rows.append(f"c\t{popu}\t{chr_name}\t{P(s)}\t{P(e)}\t{cn}\t{m}")
+    return rows
+
+
+def snp_rows(chr_name: str, length: int, every: int, seed: int) -> list:
+    """6-column SNP rows (the reference's testData/snp.txt format), both strands, one every `every`..2*`every` bases."""
+    rows = []
+    x = seed
+    pos = 137
+    i = 0
+    while pos < length - 200:
+        x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        a, b = [("A", "C"), ("C", "T"), ("A", "G"), ("G", "T"), ("C", "G"), ("A", "T")][(x >> 33) % 6]
+        strand = "+" if (x >> 40) & 1 else "-"
+        ref = a if (x >> 41) & 1 else b
+        rows.append(f"rs{i}\t{chr_name}\t{pos}\t{a}/{b}\t{strand}\t{ref}")
+        pos += every + int((x >> 45) % every)
+        i += 1
+    return rows
