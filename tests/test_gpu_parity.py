@@ -176,3 +176,30 @@ def test_ranks_owning_whole_chromosomes(name, tmp_path):
     out_dir = [l.split("=", 1)[1].strip() for l in open(cfg) if l.startswith("output")][0]
     for f in _files(one):
         assert sorted(_records(open(os.path.join(out_dir, f), "rb").read())) == sorted(_records(open(os.path.join(one, f), "rb").read())), f
+
+
+@pytest.mark.parametrize("workload", ["c3", "c4"])
+def test_bench_strong_scaling_modes(workload):
+    """bench.py --workload c3 / c4 (the whole run of a 24-contig genome per step; c4: four populations with variants):
+    one rank and two ranks sharing the device (gloo rehearsal of the RCCL exchange) sample the same number of pairs, the
+    number the configuration asks for."""
+    import json
+    import sys
+    from simuscop_amd import synth
+    scale = 0.02
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--scale", str(scale), "--steps", "1", "--warmup", "0",
+            "--no-cpu-baseline"]
+    lines = []
+    for extra, env in (([], {}), (["--gpus", "2", "--backend", "gloo"], {"BENCH_SAME_DEVICE": "1"})):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]))
+    one, two = lines
+    assert (one["n_gpus"], two["n_gpus"]) == (1, 2) and one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["workload"].startswith(workload.upper())
+    pairs = one["config"]["pairs_per_step"]
+    assert pairs == two["config"]["pairs_per_step"] == sum(r["pairs_per_step"] for r in two["per_rank"])
+    coverage = 60 if workload == "c4" else 30
+    want = sum(length for _, length in synth.grch38_contigs(scale)) * coverage / 151 / 2
+    assert abs(pairs - want) < 0.02 * want      # ceil(n/2) pairs per window: a little above reads / 2
+    assert all(r["pairs_per_step"] > 0 for r in two["per_rank"])
