@@ -1,6 +1,7 @@
 // host/fasta.cpp -- see fasta.h.
 #include "fasta.h"
 
+#include <chrono>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -157,19 +158,36 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
   void* stage[2] = {nullptr, nullptr};
   try {
     // ---- 1. stream the file image to HBM: reader threads fill one pinned buffer while the other copies
+    const bool trace = getenv("SIMU_TRACE_LOAD") != nullptr;   // phase times of the ingest on stderr
+    using Clk = std::chrono::steady_clock;
+    auto secs = [](Clk::time_point a) { return std::chrono::duration<double>(Clk::now() - a).count(); };
+    auto t_ph = Clk::now();
     eng_check(ctx, sg_reference_begin(ctx, size), "sg_reference_begin");
+    const double t_begin = secs(t_ph);
+    t_ph = Clk::now();
     const uint64_t kChunk = 64u << 20;
     for (int i = 0; i < 2 && size; i++) {
       eng_check(ctx, sg_host_alloc(ctx, std::min<uint64_t>(kChunk, size), &stage[i]), "sg_host_alloc");
     }
+    const double t_pin = secs(t_ph);
+    double t_read = 0, t_wait = 0;
+    t_ph = Clk::now();
     int cur = 0;
     for (uint64_t off = 0; off < size; off += kChunk, cur ^= 1) {
       const uint64_t n = std::min<uint64_t>(kChunk, size - off);
+      auto t1 = Clk::now();
       parallel_pread(fd, (uint8_t*)stage[cur], off, n, threads);  // overlaps the copy of the other buffer
+      t_read += secs(t1);
+      t1 = Clk::now();
       eng_check(ctx, sg_sync(ctx), "sg_sync");                    // the other buffer's copy is done: it is free next round
+      t_wait += secs(t1);
       eng_check(ctx, sg_reference_chunk(ctx, off, stage[cur], n), "sg_reference_chunk");
     }
     eng_check(ctx, sg_sync(ctx), "sg_sync");
+    if (trace)
+      fprintf(stderr, "load trace: device buffer %.3fs, pinned staging %.3fs, stream %.3fs (pread %.3fs, waiting for copies %.3fs) of %.2f GB\n",
+              t_begin, t_pin, secs(t_ph), t_read, t_wait, size / 1e9);
+    t_ph = Clk::now();
     // ---- 2. header offsets from the device scan; header text and line shape from a few small preads
     std::vector<uint64_t> hdr(1u << 16);
     uint32_t found = 0, flags = 0;
@@ -200,6 +218,7 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
       streamed = true;
       ok = true;
     }
+    if (trace) fprintf(stderr, "load trace: header scan, line shapes and ingest kernel %.3fs\n", secs(t_ph));
   } catch (...) {
     ::close(fd);
     for (void* b : stage) if (b) sg_host_free(ctx, b);
