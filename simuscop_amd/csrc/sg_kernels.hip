@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 // fragments t = j, j+PLAN_S, ... independently.  Windows near a chain end keep the sequential loop
 // on lane 0.
 // ------------------------------------------------------------------------------------------------
-#define PLAN_S 8
+#define PLAN_S 16
 
 __device__ __forceinline__ bool plan_attempt(const DevProfile& P, const DevBatch& B, const sg_window& win, uint64_t w,
                                              uint32_t attempt, uint64_t clen, uint32_t c3, PairRec& r, const uint32_t* isz_row,
