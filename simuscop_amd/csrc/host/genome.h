@@ -90,15 +90,21 @@ struct Genome {
   bool device_haps = false;
   ::sg_ctx* engine = nullptr;
   double t_reference = 0;  // seconds spent in Fasta::open / open_on_device
-  // Multi-GPU, ranks own whole chromosomes: owner[i] = rank of chromosomes[i] (empty: all here).  Only
-  // the owned contigs are ingested, cut into haplotype chains, scanned and sampled by this process.
+  // Multi-GPU, ranks own whole chromosomes: owner_of[name] = rank of that contig (empty: all here).  Only
+  // the owned contigs are ingested, cut into haplotype chains, scanned and sampled by this process.  Keyed by name:
+  // `chromosomes` is re-made in target-map order for runs with a BED file (generate_segments), the assignment is not.
   int shard_rank = 0, shard_world = 1;
   bool shard_contigs = false;
-  std::vector<int> owner;
+  std::map<std::string, int> owner_of;
   bool owns(const std::string& chr) const {
-    if (owner.empty()) return true;
-    const size_t i = (size_t)(std::find(chromosomes.begin(), chromosomes.end(), chr) - chromosomes.begin());
-    return i < owner.size() && owner[i] == shard_rank;
+    if (owner_of.empty()) return true;
+    const auto it = owner_of.find(chr);
+    return it != owner_of.end() && it->second == shard_rank;
+  }
+  void set_owners(const std::vector<std::string>& names, const std::vector<uint64_t>& lengths) {
+    const std::vector<int> r = assign_contigs(lengths, shard_world);
+    owner_of.clear();
+    for (size_t i = 0; i < names.size(); i++) owner_of[names[i]] = r[i];
   }
   // Longest-first greedy assignment of contigs to `world` ranks by length (ties: file order, lowest rank): the read
   // count of a chromosome follows its GC-weighted length, which follows its length.

@@ -258,7 +258,7 @@ struct Driver {
         }
         chr_wl.push_back(c);
       }
-      if (!genome.owner.empty()) {
+      if (!genome.owner_of.empty()) {
         // the other ranks' chromosomes: one small exchange per population (RCCL / gloo all-reduce in the torchrun front
         // end, the parent's pipes under `simuReads --gpus N`); each entry has one owner, so the sum is exact
         if (!opt.exchange) throw Error("ERROR: chromosome sharding needs an exchange callback (simu_options.exchange)");

@@ -185,10 +185,10 @@ void Genome::load_data() {
     // ranks own whole contigs: ingest only those (the index comes from the .fai or a host header scan)
     std::vector<uint64_t> lens;
     for (const std::string& k : fa.names) lens.push_back(fa.contigs[fa.contig_of.at(k)].length);
-    owner = assign_contigs(lens, shard_world);
+    set_owners(fa.names, lens);
     std::vector<char> owned(fa.contigs.size(), 0);
     for (size_t i = 0; i < fa.names.size(); i++)
-      if (owner[i] == shard_rank) owned[fa.contig_of.at(fa.names[i])] = 1;
+      if (owns(fa.names[i])) owned[fa.contig_of.at(fa.names[i])] = 1;
     fa.open_owned_on_device(cfg.str["ref"], engine, threads, owned);
     sharded_ingest = true;
   }
@@ -198,7 +198,7 @@ void Genome::load_data() {
     if (shard_contigs && shard_world > 1) {  // ingest replicated (host haplotypes, or not a plain FASTA): planning and sampling still sharded
       std::vector<uint64_t> lens;
       for (const std::string& k : fa.names) lens.push_back((uint64_t)fa.length(k));
-      owner = assign_contigs(lens, shard_world);
+      set_owners(fa.names, lens);
     }
   }
   t_reference = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

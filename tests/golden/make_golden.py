@@ -6,8 +6,9 @@ g++ on the reference's own sources where they lie) and runs it on every case of 
 under oracle/fakeclock.c (frozen wall clock => frozen RNG seeds) with threads = 1.  Only md5 sums,
 sizes and read counts are kept (data, not source).
 
-    python tests/golden/make_golden.py [case ...]     named cases (default: every case of cases.CASES)
-    python tests/golden/make_golden.py --slow          also the full-coverage C3 / C4 cases (cases.SLOW_CASES: minutes each)
+    python tests/golden/make_golden.py [case ...]     named cases (default: every case of cases.CASES and of
+                                                      cases.SHIPPED_CASES, the reference's own testData fixtures)
+    python tests/golden/make_golden.py --slow          also the full-coverage C3 / C4 / C0 cases (cases.SLOW_CASES: minutes each)
 """
 import hashlib
 import json
@@ -35,7 +36,7 @@ def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
     ref = os.path.join(ROOT, "oracle", "_ref", "simuReads")
     shim = os.path.join(ROOT, "oracle", "_ref", "libfakeclock.so")
-    only = [a for a in sys.argv[1:] if a != "--slow"] or list(cases.CASES)
+    only = [a for a in sys.argv[1:] if a != "--slow"] or list(cases.CASES) + list(cases.SHIPPED_CASES)
     if "--slow" in sys.argv:
         only += [n for n in cases.SLOW_CASES if n not in only]
     path = os.path.join(HERE, "golden.json")

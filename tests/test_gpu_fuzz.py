@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMU = os.path.join(ROOT, "simuscop_amd", "lib", "simuReads")
 
 
-def _make(rng, wd, extended=False):
+def _make(rng, wd, extended=False, tight_targets=False):
     fa = os.path.join(wd, "ref.fa")
     n_contigs = rng.choice([1, 1, 2, 3, 5])
     contigs = [("chr%d" % (i + 1), rng.choice([900, 4000, 30000, 90000, 250000, 1200000])) for i in range(n_contigs)]
@@ -47,7 +47,18 @@ def _make(rng, wd, extended=False):
                              indel_scale=rng.choice([None, None, 3.0, 12.0]))
         kv["profile"] = prof2
         kv["insertSize"] = max(kv["insertSize"], 900)
-    if extended:
+    if tight_targets:   # exome whose targets overlap after the +-50 bp padding, nest, abut, come unsorted (cases._bed_tight)
+        rows = []
+        for name, length in contigs:
+            if length >= 90000 and (name == big[0] or rng.random() < 0.5):
+                rows += cases._bed_tight(name[3:] if rng.random() < 0.5 else name, length, rng.randrange(1, 999), rng.choice([8, 40, 150]),
+                                         shuffle=rng.random() < 0.7)
+        if rows:
+            if rng.random() < 0.5:
+                rng.shuffle(rows)   # contigs interleaved in the file
+            cases._write(os.path.join(wd, "targets.bed"), rows)
+            kv["target"] = os.path.join(wd, "targets.bed")
+    elif extended:
         if rng.random() < 0.4 and big[1] >= 90000:   # exome: BED targets on the largest contig
             cases._write(os.path.join(wd, "targets.bed"), cases._bed(big[0][3:] if rng.random() < 0.5 else big[0], big[1], rng.randrange(1, 99), rng.choice([3, 20, 60])))
             kv["target"] = os.path.join(wd, "targets.bed")
@@ -67,19 +78,20 @@ def _make(rng, wd, extended=False):
 
 
 def _seeds():
-    """default: the 88 committed seeds; SIMU_FUZZ_SEEDS=a-b widens the hunt (seeds >= 200 add targets / mixtures)"""
+    """default: the committed seeds; SIMU_FUZZ_SEEDS=a-b widens the hunt (seeds >= 200 add targets / mixtures, seeds >= 1000
+    are exome runs with overlapping / nested / unsorted targets)"""
     env = os.environ.get("SIMU_FUZZ_SEEDS")
     if env:
         a, b = env.split("-")
         return list(range(int(a), int(b) + 1))
-    return list(range(101, 149)) + list(range(201, 261))
+    return list(range(101, 149)) + list(range(201, 261)) + list(range(1001, 1031))
 
 
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("case_seed", _seeds())
 def test_random_configuration(case_seed, oracle_lib, tmp_path):
     rng = random.Random(case_seed)
-    cfg = _make(rng, str(tmp_path), extended=case_seed >= 200)
+    cfg = _make(rng, str(tmp_path), extended=case_seed >= 200, tight_targets=case_seed >= 1000)
     seed = rng.getrandbits(63)
     odir, gdir = str(tmp_path / "o"), str(tmp_path / "g")
     rc = oracle_lib.orc_simulate(cfg.encode(), 1, seed >> 32, seed & 0xFFFFFFFF, odir.encode(), 4)

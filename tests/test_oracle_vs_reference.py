@@ -24,12 +24,10 @@ def _md5(path):
     return h.hexdigest()
 
 
-SLOW = sorted(cases.SLOW_CASES) if os.environ.get("SIMU_SLOW_TESTS") else []
-
-
-@pytest.mark.parametrize("name", sorted(cases.CASES) + SLOW)
+@pytest.mark.parametrize("name", sorted(cases.CASES))
 def test_oracle_mt_reproduces_reference(name, oracle_lib, tmp_path):
-    """(The full-coverage C3 / C4 cases take minutes on the sequential mt mode: run them with SIMU_SLOW_TESTS=1.)"""
+    """(The full-coverage C3 / C4 cases and the shipped-fixture cases take minutes on the sequential mt mode: they run in
+    the background of the same session, tests/test_zz_long_oracle_cases.py.)"""
     assert name in GOLDEN, "run tests/golden/make_golden.py"
     cfg = cases.build_case(name, str(tmp_path))
     g = GOLDEN[name]
