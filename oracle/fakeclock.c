@@ -9,6 +9,12 @@
  * With FAKECLOCK_SEC / FAKECLOCK_NSEC set and `threads = 1` its FASTQ output becomes a pure
  * function of (inputs, fake time), which is what the oracle restatement is pinned against.
  * Nothing of the reference is replaced: only the time source is pinned.
+ *
+ * FAKECLOCK_STEP_NSEC (default 0 = frozen): every clock_gettime call advances the fake time by that many nanoseconds, the
+ * way consecutive calls of a real clock differ.  With a frozen clock the reference's 101 GC-factor generators
+ * (Profile.cpp:1409-1415, one default_random_engine per GC%, each seeded from now()) all get the SAME seed and draw the
+ * same sequence; the statistical tests of the GC law (tests/test_gpu_histograms.py) step the clock so that the reference
+ * runs the way it does in the field.  The md5 pins keep the frozen clock.
  */
 #define _GNU_SOURCE
 #include <stdlib.h>
@@ -18,10 +24,16 @@
 static long fk_sec(void)  { const char *s = getenv("FAKECLOCK_SEC");  return s ? atol(s) : 1500000000L; }
 static long fk_nsec(void) { const char *s = getenv("FAKECLOCK_NSEC"); return s ? atol(s) : 123456789L; }
 
+static long fk_step(void) { const char *s = getenv("FAKECLOCK_STEP_NSEC"); return s ? atol(s) : 0L; }
+
 int clock_gettime(clockid_t id, struct timespec *ts) {
+  static unsigned long calls = 0;
   (void)id;
-  ts->tv_sec = fk_sec();
-  ts->tv_nsec = fk_nsec();
+  const long step = fk_step();
+  const unsigned long k = step ? __atomic_fetch_add(&calls, 1UL, __ATOMIC_RELAXED) : 0UL;
+  const unsigned long long ns = (unsigned long long)fk_nsec() + (unsigned long long)step * k;
+  ts->tv_sec = fk_sec() + (long)(ns / 1000000000ULL);
+  ts->tv_nsec = (long)(ns % 1000000000ULL);
   return 0;
 }
 time_t time(time_t *t) {
