@@ -499,9 +499,11 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     // (1) the LDS image, per mate and bin: [0,192) keep_h - 1 of the context's row, keep_h = c0 >> 16 (a 16-bit head
     //     below keep_h is certainly "no substitution"); [192, 192 + 4W) the diagonal alias columns (reference base ==
     //     called base) in the order [col][natural base] as  col << (16 - lgW) | thr >> 16  in the low half (the draw's
-    //     low half minus it is u_head - thr_head: the column bits cancel),  (lo ^ hi) << 16 | hi << 24  above
+    //     low half minus it is u_head - thr_head: the column bits cancel),  (lo ^ hi) << 16 | hi << 24  above, lo and hi as
+    //     characters (symbol + the profile's lowest quality character)
     fast_lds_off = tab.size();
     tab.resize(fast_lds_off + (size_t)n_mates * bins * fast_stride);
+    const uint32_t mq = (uint32_t)pr->min_qual;
     for (int t = 0; t < n_mates; t++)
       for (int b = 0; b < bins; b++) {
         uint32_t* blk = &tab[fast_lds_off + ((size_t)t * bins + b) * fast_stride];
@@ -510,7 +512,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
           const uint32_t pc = prof_of(cdn);
           const sg::AliasRow& ar = arows[((size_t)pc * 4 + pc) * bins + b];
           for (uint32_t c = 0; c < W; c++)
-            blk[192 + c * 4 + cdn] = (c << (16 - lgW)) | (ar.thr[c] >> 16) | (uint32_t)(ar.lo[c] ^ ar.hi[c]) << 16 | (uint32_t)ar.hi[c] << 24;
+            blk[192 + c * 4 + cdn] = (c << (16 - lgW)) | (ar.thr[c] >> 16) | (uint32_t)((ar.lo[c] + mq) ^ (ar.hi[c] + mq)) << 16 | (uint32_t)(ar.hi[c] + mq) << 24;
         }
       }
     // (2) full substitution rows for the kernel's fix-up path: [mate][bin][192] x {D0, D1, D2, j0 | n0<<2 | .. | n3<<8}

@@ -966,6 +966,54 @@ __device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h
   return l == 0u ? y[0] : l == 1u ? y[1] : l == 2u ? y[2] : y[3];
 }
 
+// The 8-base block of the straight-line kernels: eight positions' substitution and quality decisions from their heads
+// words.  Every VALU instruction costs about the same here (~4.2 cycles in this mix), so the block is written for few
+// instructions: 16-bit fields that operand selects (SDWA) pick for free, byte permutes for packing.
+//   cw   13 source codes, 2 bits each (output positions i0-5 .. i0+7)      x[h]  heads word of position i0 + h
+//   so[h] byte offset of position h's bin in the table image (+ the short-context region of a read's first two bases),
+//   qo0/qo1 the plain bin offsets of positions 0 and 1
+// Out: sw = the eight called characters (= the reference bases), qw = the eight quality characters, acc bit 17 + h = the
+// head could not decide base h (possible substitution, or a head equal to a threshold's): the fix-up pass redoes it.
+__device__ __forceinline__ void sample8(const uint32_t* img, const uint32_t* code4, uint32_t lgW, uint32_t cw, const uint32_t (&x)[8],
+                                        const uint32_t (&so)[8], uint32_t qo0, uint32_t qo1, uint32_t (&sw)[2], uint32_t (&qw)[2],
+                                        uint32_t& acc_out) {
+  const uint8_t* img_b = (const uint8_t*)img;
+  // the items's eight reference codes as bytes code * 4 (alias column offset, and >> 2 the character selector)
+  const uint32_t cd4[2] = {code4[(cw >> 10) & 0xFFu], code4[(cw >> 18) & 0xFFu]};
+  const uint32_t col_at = 16u - lgW;
+  uint32_t acc = 0, sy[8];
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    const uint32_t wh = x[h];
+    // substitution: sure "none" iff the 16-bit head (high half) is below the row's keep count: d_s = keep_h - 1 - head >= 0
+    const uint32_t kv = __builtin_amdgcn_ubfe(cw, 2 * h + 6, 6);
+    const uint32_t keepm1 = *(const uint32_t*)(img_b + so[h] + (kv << 2));
+    const uint32_t d_s = keepm1 - (wh >> 16);
+    // quality: alias column (col, cd) of the diagonal row; its low half holds col : thr_head, so the draw's low half minus
+    // it is d_q = u_head - thr_head: negative -> lo, positive -> hi, zero -> the tail decides (fix-up)
+    const uint32_t col = __builtin_amdgcn_ubfe(wh, col_at, lgW);
+    const uint32_t qa = (h == 0 ? qo0 : h == 1 ? qo1 : so[h]) + ((cd4[h >> 2] >> (8 * (h & 3))) & 0xFFu);
+    const uint32_t e = *(const uint32_t*)(img_b + qa + (col << 4) + FAST_CTX * 4u);
+    const uint32_t d_q = (wh & 0xFFFFu) - (e & 0xFFFFu);
+    // flag (bits 17.. are copies of it): substitution possible (d_s < 0) or head on the threshold (d_q == 0)
+    const uint32_t z = __builtin_amdgcn_bitop3_b32(d_q - 1u, d_q, d_s, BITOP_ANDN_OR);
+    acc = __builtin_amdgcn_bitop3_b32(acc, z, 1u << (17 + h), BITOP_OR_AND);
+    // symbol = hi ^ ((lo ^ hi) & (d_q < 0)), fields at bits 24.. and 16..: lands in byte 2 (the image holds the symbols as
+    // characters: the profile's lowest quality character is added on the host)
+    sy[h] = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
+  }
+  // byte 2 of four symbols words -> one word (selector bytes: 0-3 from the second operand, 4-7 from the first)
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const uint32_t p01 = __builtin_amdgcn_perm(sy[4 * g + 1], sy[4 * g], 0x0C0C0602u);
+    const uint32_t p23 = __builtin_amdgcn_perm(sy[4 * g + 3], sy[4 * g + 2], 0x06020C0Cu);
+    qw[g] = p01 | p23;
+    // called bases = reference bases: code -> character
+    sw[g] = __builtin_amdgcn_perm(0u, 0x47544341u, cd4[g] >> 2);  // "ACTG"
+  }
+  acc_out = acc;
+}
+
 // Base index of an item's un-shifted template window in the 2-bit copy the read walks forwards -- the forward copy, or
 // for a reverse read the reverse-complement copy, where the fragment [A, A + n) starts at total - A - n: output
 // position p of the read is base `index + p - 8c + 5` of that copy.  Idle lanes read a harmless in-bounds index.
@@ -977,13 +1025,14 @@ __device__ __forceinline__ uint32_t fast_src(const DevBatch& B, uint32_t m, cons
   return active ? a + 8u * c - 5u : 128u;
 }
 
-template <bool PAIRED>
+template <bool PAIRED, bool DIAG>
 __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint32_t* img, const uint32_t* lut,
                                           const uint32_t* code4, uint32_t TI, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint4* tail_row, int d0, uint32_t n_in,
                                           uint32_t ew_in, uint32_t tj_in, uint32_t src0, uint2 wpre,
                                           __amdgpu_buffer_rsrc_t out_rsrc, uint32_t& fix, uint32_t& cw_out) {
   const uint32_t bins = (uint32_t)P.bins;
+  const uint32_t dg = DIAG ? B.diag : 0u;  // SG_FDIAG timing ablations: compiled out of the production kernel
   const bool rev = PAIRED ? (m == 1u) : ((m1.x >> 31) != 0);
   // An idle lane may be looking at a row whose read is finished; its fragment offset, reciprocal and event word then
   // hold the parked last item (see below), so an idle lane must not follow them -- it reads a harmless in-bounds
@@ -1009,7 +1058,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   }
   const uint32_t bad = (m1.x >> 30) & 1u;
   uint32_t cw;
-  if (B.diag & 4u) cw = slot * 2654435761u + c;  // ablation: no haplotype fetch
+  if (dg & 4u) cw = slot * 2654435761u + c;  // ablation: no haplotype fetch
   else cw = (uint32_t)((((uint64_t)wpre.y << 32) | wpre.x) >> (2u * (src & 3u)));
 
   // reads with exactly one sequencing indel: past the event the window is shifted by +-len
@@ -1044,7 +1093,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   // ---- two Philox calls: the heads words of the item's eight positions (call = i/4, word = i%4) ----
   uint32_t x[8];
   const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
-  if (B.diag & 8u) {  // ablation: no Philox
+  if (dg & 8u) {  // ablation: no Philox
 #pragma unroll
     for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
   } else {
@@ -1074,49 +1123,13 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     qo0 = so[0]; qo1 = so[1];
     if (c == 0u) { so[0] += 128u * 4u; so[1] += 64u * 4u; }
   }
-  // ---- the 8-base block.  Every VALU instruction costs about the same here (~4.2 cycles in this mix), so the block is
-  // written for few instructions: 16-bit fields that operand selects (SDWA) pick for free, byte permutes for packing. ----
-  const uint8_t* img_b = (const uint8_t*)img;
-  // the items's eight reference codes as bytes code * 4 (alias column offset, and >> 2 the character selector)
-  const uint32_t cd4[2] = {code4[(cw >> 10) & 0xFFu], code4[(cw >> 18) & 0xFFu]};
-  const uint32_t col_at = 16u - lgW;
-  uint32_t acc = 0, sy[8];
-#pragma unroll
-  for (int h = 0; h < 8; h++) {
-    const uint32_t wh = x[h];
-    // substitution: sure "none" iff the 16-bit head (high half) is below the row's keep count: d_s = keep_h - 1 - head >= 0
-    const uint32_t kv = __builtin_amdgcn_ubfe(cw, 2 * h + 6, 6);
-    const uint32_t keepm1 = *(const uint32_t*)(img_b + so[h] + (kv << 2));
-    const uint32_t d_s = keepm1 - (wh >> 16);
-    // quality: alias column (col, cd) of the diagonal row; its low half holds col : thr_head, so the draw's low half minus
-    // it is d_q = u_head - thr_head: negative -> lo, positive -> hi, zero -> the tail decides (fix-up)
-    const uint32_t col = __builtin_amdgcn_ubfe(wh, col_at, lgW);
-    const uint32_t qa = (h == 0 ? qo0 : h == 1 ? qo1 : so[h]) + ((cd4[h >> 2] >> (8 * (h & 3))) & 0xFFu);
-    const uint32_t e = *(const uint32_t*)(img_b + qa + (col << 4) + FAST_CTX * 4u);
-    const uint32_t d_q = (wh & 0xFFFFu) - (e & 0xFFFFu);
-    // flag (bits 17.. are copies of it): substitution possible (d_s < 0) or head on the threshold (d_q == 0)
-    const uint32_t z = __builtin_amdgcn_bitop3_b32(d_q - 1u, d_q, d_s, BITOP_ANDN_OR);
-    acc = __builtin_amdgcn_bitop3_b32(acc, z, 1u << (17 + h), BITOP_OR_AND);
-    // symbol = hi ^ ((lo ^ hi) & (d_q < 0)), fields at bits 24.. and 16..: lands in byte 2
-    sy[h] = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
-  }
-  // byte 2 of four symbols words -> one word (selector bytes: 0-3 from the second operand, 4-7 from the first)
-  uint32_t qw[2], sw[2];
-#pragma unroll
-  for (int g = 0; g < 2; g++) {
-    const uint32_t p01 = __builtin_amdgcn_perm(sy[4 * g + 1], sy[4 * g], 0x0C0C0602u);
-    const uint32_t p23 = __builtin_amdgcn_perm(sy[4 * g + 3], sy[4 * g + 2], 0x06020C0Cu);
-    qw[g] = p01 | p23;
-    // called bases = reference bases: code -> character
-    sw[g] = __builtin_amdgcn_perm(0u, 0x47544341u, cd4[g] >> 2);  // "ACTG"
-  }
+  uint32_t qw[2], sw[2], acc;
+  sample8(img, code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
   const bool slow = active && (bad != 0u || nev >= 2u);  // queued for the generic item code by the caller
   // flagged bases are redone exactly by the group's fix-up pass (the flags of a queued item do not matter)
-  fix = (active && !slow && !(B.diag & 16u)) ? (acc >> 17) & 0xFFu & ((1u << min(8u, np - i0)) - 1u) : 0u;
+  fix = (active && !slow && !(dg & 16u)) ? (acc >> 17) & 0xFFu & ((1u << min(8u, np - i0)) - 1u) : 0u;
   cw_out = cw;
   const bool go = active && !slow;
-  qw[0] += 0x01010101u * (uint32_t)P.min_qual;
-  qw[1] += 0x01010101u * (uint32_t)P.min_qual;
   // A whole item is two 8-byte stores.  They are buffer stores through the read group's descriptor (base = the group's
   // first record, offsets 32-bit), issued by EVERY lane on every path: a lane with nothing to store gives an offset past
   // the descriptor's range and the hardware drops it.  The step loop so holds a fixed number of vector-memory
@@ -1131,7 +1144,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   {
     const bool last7 = i0 + 7u == np;
     const bool whole = i0 + 8u <= np || last7;
-    const bool st = go && whole && !(B.diag & 1u);
+    const bool st = go && whole && !(dg & 1u);
     const uint32_t so_ = st ? m0.z + hdr + i0 : 0xFFFFFFFFu;
     const uint32_t qo_ = st ? so_ + np + 3u : 0xFFFFFFFFu;
     const uint32_t s1 = last7 ? (sw[1] & 0x00FFFFFFu) | 0x0A000000u : sw[1];
@@ -1161,9 +1174,10 @@ __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, 
 }
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
+#define OVF_CAP 192   // per-wave list of single items: the plain reads' last items (<= 63) + appended items (<= 126)
 #define FIX_CAP 128   // per-wave list of flagged bases waiting for the group's fix-up pass
 
-template <bool PAIRED>
+template <bool PAIRED, bool DIAG>
 __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t TI, uint32_t inv_TI) {
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -1176,6 +1190,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     return;
   }
   const uint32_t bins = (uint32_t)P.bins;
+  const uint32_t dg = DIAG ? B.diag : 0u;  // SG_FDIAG timing ablations: compiled out of the production kernel
   // ---- LDS: [table image: bins x fast_stride words][look-up rows: TI x 12][256 words: four 2-bit codes -> bytes code * 4]
   //           [per-wave read rows][slow-item queues][fix-up lists][read order][appended items] ----
   const uint32_t img_words = bins * P.fast_stride;
@@ -1186,7 +1201,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint32_t* slow_all = (uint32_t*)(lds_meta_all + EMIT_WAVES * 64 * (META_ROW / 16));
   uint2* fix_all = (uint2*)(slow_all + EMIT_WAVES * SLOW_CAP);
   uint8_t* perm_all = (uint8_t*)(fix_all + EMIT_WAVES * FIX_CAP);
-  uint16_t* ovf_all = (uint16_t*)(perm_all + EMIT_WAVES * 64);  // items just past the stream map (read | item << 8)
+  uint8_t* permp_all = perm_all + EMIT_WAVES * 64;                  // the plain reads of a group, in lane order
+  uint16_t* ovf_all = (uint16_t*)(permp_all + EMIT_WAVES * 64);     // single items of the general stream (read | item << 8)
   {
     const uint4* src = (const uint4*)(P.fast_lds + (size_t)tm * P.fast_mate_words);  // 16-byte aligned on the host
     for (uint32_t i = tid; i < (img_words + 3u) / 4u; i += EMIT_THREADS) ((uint4*)img)[i] = src[i];
@@ -1212,7 +1228,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint32_t* slow_list = slow_all + wv * SLOW_CAP;
   uint2* fix_list = fix_all + wv * FIX_CAP;
   uint8_t* perm = perm_all + wv * 64;
-  uint16_t* ovf = ovf_all + wv * 128;
+  uint8_t* permp = permp_all + wv * 64;
+  uint16_t* ovf = ovf_all + wv * OVF_CAP;
+  const uint32_t TIp = TI - 1u;                          // items per plain read that run through the plain steps
+  const uint32_t inv_TIp = TIp ? (1u << 20) / TIp + 1u : 0u;  // ceil-reciprocal (i / TIp exact while i * TIp < 2^20)
 
   // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one
   // stream, 64 per step: lane l of step s does stream item i = 64 s + l = item i % TI of the (i / TI)-th read in step
@@ -1236,7 +1255,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         items = ((my1.y & 0xFFFFu) + 7u) / 8u;  // separators: per-read pass below
         // The read's name, stored in front of where the step loop will put the bases: the batch's prefix, then the
         // read's own part from its row (indel_kernel made the text), two pieces of <= 16 bytes.
-        if (B.prefix_len <= 16u && !(B.diag & 2u)) {
+        if (B.prefix_len <= 16u && !(dg & 2u)) {
           uint8_t* rec = B.out[m] + ooff;
           const uint32_t nv = (my1.y >> 22) - B.prefix_len;
           if (__builtin_expect(nv > 16u, 0)) {
@@ -1260,7 +1279,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     uint8_t* const gout = B.out[m] + gbase;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(gout, 0, 0x80000000u, 0x00020000);
     my0.z = (uint32_t)(ooff - gbase);
-    my0.w = 0;
+    {
+      // what the plain steps need of the read, in the two row words nothing else uses: the base index of output position -5
+      // in the 2-bit copy the read walks (bit 31: that copy is the reverse complement), the offset of its first base
+      const uint32_t flen_l = my1.x & 0x3FFFFFFFu;
+      const bool rev_l = PAIRED ? (m == 1u) : ((my1.x >> 31) != 0u);
+      my0.y = ((rev_l ? (uint32_t)B.chains_total - my0.x - flen_l : my0.x) - 5u) | (rev_l ? 0x80000000u : 0u);
+      my0.w = my0.z + (my1.y >> 22);
+    }
     meta_rows[lane * 2] = my0;
     meta_rows[lane * 2 + 1] = my1;
     wave_lds_sync();
@@ -1297,83 +1323,112 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint4* gsub = P.fast_sub + (size_t)tm * bins * FAST_CTX;
       const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
       for (uint32_t b0 = 0; b0 < nfix; b0 += 64u) {
-        const bool on = b0 + lane < nfix;
-        const uint2 fe = fix_list[on ? b0 + lane : 0u];
-        const uint32_t r = fe.x & 63u, h = (fe.x >> 6) & 7u, bin = (fe.x >> 9) & 0xFFu, c = fe.x >> 17, cw = fe.y;
+        // lane = flagged item: read | flags of its eight bases << 6 | item << 17, packed codes; its bases one after the
+        // other (nine items in ten have one flagged base, so the loop body nearly always runs once per 64 items)
+        const uint2 fe = fix_list[b0 + lane < nfix ? b0 + lane : 0u];
+        uint32_t todo = b0 + lane < nfix ? (fe.x >> 6) & 0xFFu : 0u;
+        const uint32_t r = fe.x & 63u, c = fe.x >> 17, cw = fe.y;
         const uint32_t slot = g * G + r + B.slot_offset;
-        uint32_t xw[4];
-        philox4x32_10(slot, 2u * c + (h >> 2), 0, c3b, B.k0, B.k1, xw);
-        const uint32_t l = h & 3u;
-        const uint32_t wh = l == 0u ? xw[0] : l == 1u ? xw[1] : l == 2u ? xw[2] : xw[3];
-        const uint32_t region = c == 0u ? (h == 0u ? 128u : h == 1u ? 64u : 0u) : 0u;
-        const uint32_t cdn = (cw >> (2u * h + 10u)) & 3u;
-        const uint4 row = gsub[(size_t)bin * FAST_CTX + region + ((cw >> (2u * h + 6u)) & 63u)];
-        // identity-first row on the 16-bit head: certain unless the head equals a threshold's
-        const uint32_t sh = wh >> 16, h0 = row.x >> 16, h1 = row.y >> 16, h2 = row.z >> 16;
-        const uint32_t jj = (uint32_t)(sh > h0) + (uint32_t)(sh > h1) + (uint32_t)(sh > h2);
-        const bool amb_s = on && jj != (uint32_t)(sh >= h0) + (uint32_t)(sh >= h1) + (uint32_t)(sh >= h2);
-        uint32_t kn = 0;
-        uint2 e2 = make_uint2(0, 0);
-        const uint32_t col = (wh & 0xFFFFu) >> (16u - lgW), uh = wh & u_mask;
-        auto column = [&](uint32_t j_) {
-          const uint32_t jm = max(j_, row.w & 3u);
-          kn = (row.w >> (2u * jm + 2u)) & 3u;
-          e2 = P.fast_alias[((((size_t)cdn * 4u + kn) * bins + bin) << lgW) + col];
-        };
-        if (!amb_s) column(jj);
-        const bool need_tail = amb_s || (on && uh == (e2.x >> 16) && (e2.y & 0xFFu) != (e2.y >> 8));
-        uint32_t wt = 0;
-        if (__ballot(need_tail) != 0ull) {
-          if (need_tail) wt = tail_word(slot, c, h, c3b, B.k0, B.k1);
-        }
-        if (__ballot(amb_s) != 0ull) {
-          if (amb_s) {
-            const uint32_t xs = (wh & 0xFFFF0000u) | (wt >> 16);
-            column((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z));
+        const uint4 r0 = meta_rows[r * 2], r1 = meta_rows[r * 2 + 1];
+        const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
+        // stored like a whole item (a last item of seven bases included), or the read's parked last item?
+        const bool whole = 8u * c + 8u <= np + (uint32_t)((np & 7u) == 7u);
+        // ceil(2^32 / n') again (indel_kernel's row word): a read's parked last item has overwritten it in the row
+        const uint32_t inv = 0xFFFFFFFFu / max(np, 1u) + 1u;
+        while (__ballot(todo != 0u) != 0ull) {
+          const bool on = todo != 0u;
+          const uint32_t h = on ? (uint32_t)__builtin_ctz(todo) : 0u;
+          todo &= todo - 1u;
+          const uint32_t i = 8u * c + h;
+          const uint32_t bin = __umulhi(__umul24(i, bins), inv);
+          uint32_t xw[4];
+          philox4x32_10(slot, 2u * c + (h >> 2), 0, c3b, B.k0, B.k1, xw);
+          const uint32_t l = h & 3u;
+          const uint32_t wh = l == 0u ? xw[0] : l == 1u ? xw[1] : l == 2u ? xw[2] : xw[3];
+          const uint32_t region = c == 0u ? (h == 0u ? 128u : h == 1u ? 64u : 0u) : 0u;
+          const uint32_t cdn = (cw >> (2u * h + 10u)) & 3u;
+          const uint4 row = gsub[(size_t)bin * FAST_CTX + region + ((cw >> (2u * h + 6u)) & 63u)];
+          // identity-first row on the 16-bit head: certain unless the head equals a threshold's
+          const uint32_t sh = wh >> 16, h0 = row.x >> 16, h1 = row.y >> 16, h2 = row.z >> 16;
+          const uint32_t jj = (uint32_t)(sh > h0) + (uint32_t)(sh > h1) + (uint32_t)(sh > h2);
+          const bool amb_s = on && jj != (uint32_t)(sh >= h0) + (uint32_t)(sh >= h1) + (uint32_t)(sh >= h2);
+          uint32_t kn = 0;
+          uint2 e2 = make_uint2(0, 0);
+          const uint32_t col = (wh & 0xFFFFu) >> (16u - lgW), uh = wh & u_mask;
+          auto column = [&](uint32_t j_) {
+            const uint32_t jm = max(j_, row.w & 3u);
+            kn = (row.w >> (2u * jm + 2u)) & 3u;
+            e2 = P.fast_alias[((((size_t)cdn * 4u + kn) * bins + bin) << lgW) + col];
+          };
+          if (!amb_s) column(jj);
+          const bool need_tail = amb_s || (on && uh == (e2.x >> 16) && (e2.y & 0xFFu) != (e2.y >> 8));
+          uint32_t wt = 0;
+          if (__ballot(need_tail) != 0ull) {
+            if (need_tail) wt = tail_word(slot, c, h, c3b, B.k0, B.k1);
           }
-        }
-        // side of the column: the head decides unless it sits on the threshold's (then the 16-bit tail does)
-        const uint32_t th = e2.x >> 16;
-        const bool lo_side = uh != th ? uh < th : ((uh << 16) | (wt & 0xFFFFu)) < e2.x;
-        const uint32_t sym = (lo_side ? (e2.y & 0xFFu) : (e2.y >> 8)) + (uint32_t)P.min_qual;
-        const uint32_t ch = (0x47544341u >> (8u * kn)) & 0xFFu;  // "ACTG"[kn]: natural code -> character
-        if (on) {
-          const uint4 r0 = meta_rows[r * 2], r1 = meta_rows[r * 2 + 1];
-          const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22, i = 8u * c + h;
-          if (8u * c + 8u <= np + (uint32_t)((np & 7u) == 7u)) {  // (a last item of seven bases was stored like a whole one)
-            uint8_t* rec = gout + r0.z + hl + i;
-            rec[0] = (uint8_t)ch;
-            rec[np + 3u] = (uint8_t)sym;
-          } else if (r0.x != 0xFFFFFFFFu) {
-            // the read's parked last item: characters in words 0, 1, qualities in words 6, 7 of its row
-            uint8_t* row8 = (uint8_t*)(meta_rows + r * 2);
-            row8[h] = (uint8_t)ch;
-            row8[24u + h] = (uint8_t)sym;
+          if (__ballot(amb_s) != 0ull) {
+            if (amb_s) {
+              const uint32_t xs = (wh & 0xFFFF0000u) | (wt >> 16);
+              column((uint32_t)(xs > row.x) + (uint32_t)(xs > row.y) + (uint32_t)(xs > row.z));
+            }
+          }
+          // side of the column: the head decides unless it sits on the threshold's (then the 16-bit tail does)
+          const uint32_t th = e2.x >> 16;
+          const bool lo_side = uh != th ? uh < th : ((uh << 16) | (wt & 0xFFFFu)) < e2.x;
+          const uint32_t sym = (lo_side ? (e2.y & 0xFFu) : (e2.y >> 8)) + (uint32_t)P.min_qual;
+          const uint32_t ch = (0x47544341u >> (8u * kn)) & 0xFFu;  // "ACTG"[kn]: natural code -> character
+          if (on) {
+            if (whole) {
+              uint8_t* rec = gout + r0.z + hl + i;
+              rec[0] = (uint8_t)ch;
+              rec[np + 3u] = (uint8_t)sym;
+            } else if (r0.x != 0xFFFFFFFFu) {
+              // the read's parked last item: characters in words 0, 1, qualities in words 6, 7 of its row
+              uint8_t* row8 = (uint8_t*)(meta_rows + r * 2);
+              row8[h] = (uint8_t)ch;
+              row8[24u + h] = (uint8_t)sym;
+            }
           }
         }
       }
       nfix = 0;
       wave_lds_sync();
     };
-    // Order of the group's reads through the step loop: reads without a sequencing indel first, then the
-    // reads with one, then the reads with several (so that the two-window code, the event-list walk and the
-    // computed bin offsets run in the few steps that need them instead of whenever one of a step's reads has
-    // an event, 42 % of the steps at XTen rates).
+    // The group's items go through two loops.
+    //  * PLAIN steps: items 0 .. TI-2 of the plain reads -- no sequencing indel, the profile's own length, no non-ACGT
+    //    block (84 % of the reads at XTen rates).  Every such item is eight bases stored whole, its bin offsets come from
+    //    the look-up row, nothing about it is conditional: the step is the 8-base block, two Philox calls and ~50
+    //    instructions around them (the general step: ~250).
+    //  * GENERAL steps: everything else as one item stream -- all items of the other reads (reads with one indel before
+    //    those with several, so that the two-window code and the event-list walk run in few steps), then single items: the
+    //    plain reads' last items (partial or followed by the separators: the per-read pass and the parked-item logic
+    //    belong to the general code) and the one or two items an insertion appended to a read.
     const uint32_t nev_l = (my1.y >> 16) & 0x3Fu;
+    const uint32_t np_l = my1.y & 0xFFFFu;
+    const bool act_l = items > 0u;
+    const bool plain_l = act_l && nev_l == 0u && np_l == (uint32_t)P.L && items == TI && !((my1.x >> 30) & 1u) && TIp != 0u;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long in_group = (1ull << G) - 1ull;
-    const unsigned long long m_multi = __ballot(items > 0u && nev_l >= 2u);
-    const unsigned long long m_one = __ballot(items > 0u && nev_l == 1u);
-    const unsigned long long m_rest = in_group & ~(m_multi | m_one);
+    const unsigned long long m_plain = __ballot(plain_l);
+    const unsigned long long m_multi = __ballot(act_l && nev_l >= 2u);
+    const unsigned long long m_one = __ballot(act_l && nev_l == 1u);
+    const unsigned long long m_rest = __ballot(act_l && !plain_l && nev_l == 0u);
+    const uint32_t n_plain = (uint32_t)__popcll(m_plain);
     const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_one = (uint32_t)__popcll(m_one);
-    const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // all of them walk the steps
-    if (lane < G) {
-      uint32_t pos;
-      if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
-      else if ((m_one >> lane) & 1ull) pos = n_rest + (uint32_t)__popcll(m_one & lt);
-      else pos = n_rest + n_one + (uint32_t)__popcll(m_multi & lt);
-      perm[pos] = (uint8_t)lane;
+    const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // reads whose items all walk the general steps
+    if (act_l) {
+      if (plain_l) {
+        const uint32_t pos = (uint32_t)__popcll(m_plain & lt);
+        permp[pos] = (uint8_t)lane;
+        ovf[pos] = (uint16_t)(lane | (TIp << 8));   // its last item: a single item of the general stream
+      } else {
+        uint32_t pos;
+        if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
+        else if ((m_one >> lane) & 1ull) pos = n_rest + (uint32_t)__popcll(m_one & lt);
+        else pos = n_rest + n_one + (uint32_t)__popcll(m_multi & lt);
+        perm[pos] = (uint8_t)lane;
+      }
     }
+    if (n_fast == 0u && lane == 0u) perm[0] = 0;   // (what idle lanes of a step look at)
     // TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to the end of
     // the stream (they fill lanes of the last step that would idle anyway); only reads longer than that take
     // steps of their own below.
@@ -1381,15 +1436,16 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const bool small = extra == 1u || extra == 2u;
     const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
     if (small) {
-      const uint32_t o = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+      const uint32_t o = n_plain + (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
       ovf[o] = (uint16_t)(lane | (TI << 8));
       if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
     }
-    const uint32_t n_ovf = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    const uint32_t n_ovf = n_plain + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
     unsigned long long more = __ballot(extra > 2u);
     wave_lds_sync();
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
     const uint32_t nmain = (n_stream + 63u) / 64u;
+    const uint32_t n_pitems = n_plain * TIp, npsteps = (n_pitems + 63u) / 64u;
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
     // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
@@ -1446,28 +1502,86 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         }
       }
       uint32_t fix, cw;
-      const bool slow = fast_item<PAIRED>(P, B, img, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
+      const bool slow = fast_item<PAIRED, DIAG>(P, B, img, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
                                           tj_in, st.src, st.w, out_rsrc, fix, cw);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
         if (slow) slow_list[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r | (c << 8);
         nslow += (uint32_t)__popcll(sm);
       }
-      // flagged bases -> the group's fix-up list: read | base << 6 | bin << 9 | item << 17 (bins < 256: the table image
-      // would not fit LDS otherwise; items < 2^15), packed codes
-      unsigned long long fm = __ballot(fix != 0u);
-      while (fm) {
+      // flagged items -> the group's fix-up list: read | flags of the eight bases << 6 | item << 17 (items < 2^15), packed
+      // codes.  One entry per item whatever the number of its flagged bases: no loop in the step.
+      const unsigned long long fm = __ballot(fix != 0u);
+      if (fm) {
         if (nfix + 64u > FIX_CAP) flush_fix();
-        if (fix != 0u) {
-          const uint32_t h = (uint32_t)__builtin_ctz(fix);
-          fix &= fix - 1u;
-          const uint32_t bin = __umulhi(__umul24(8u * c + h, bins), m1.z);
-          fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(r | (h << 6) | (bin << 9) | (c << 17), cw);
-        }
+        if (fix != 0u) fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(r | (fix << 6) | (c << 17), cw);
         nfix += (uint32_t)__popcll(fm);
-        fm = __ballot(fix != 0u);
       }
     };
+    // ---- plain steps ----
+    if (npsteps) {
+      struct PStage { uint32_t r, c, src, out; bool ok; uint2 w; };
+      auto fetch_plain = [&](uint32_t step) -> PStage {
+        PStage st;
+        const uint32_t i_raw = step * 64u + lane;
+        st.ok = i_raw < n_pitems;
+        const uint32_t i = min(i_raw, n_pitems - 1u);     // idle lanes redo the stream's last item, their stores are dropped
+        const uint32_t ri = __umul24(i, inv_TIp) >> 20;  // i / TIp
+        st.c = i - __umul24(ri, TIp);
+        st.r = permp[ri];
+        const uint32_t* row = (const uint32_t*)(meta_rows + st.r * 2);
+        const uint32_t A = row[1];
+        st.src = (A & 0x7FFFFFFFu) + 8u * st.c;
+        st.out = row[3] + 8u * st.c;
+        const uint8_t* copy2 = (PAIRED ? m == 1u : (A >> 31) != 0u) ? B.chains2_rc : B.chains2_fwd;
+        __builtin_memcpy(&st.w, copy2 + (st.src >> 2), 8);
+        return st;
+      };
+      const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+      const uint32_t lgW = P.lgW;
+      auto run_plain = [&](const PStage& st) {
+        const uint32_t c = st.c;
+        uint32_t cw;
+        if (dg & 4u) cw = (g * G + st.r) * 2654435761u + c;  // ablation: no haplotype fetch
+        else cw = (uint32_t)((((uint64_t)st.w.y << 32) | st.w.x) >> (2u * (st.src & 3u)));
+        uint32_t x[8];
+        const uint32_t slot = g * G + st.r + B.slot_offset;
+        if (dg & 8u) {  // ablation: no Philox
+#pragma unroll
+          for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
+        } else {
+          philox4x32_10(slot, 2u * c, 0, c3b, B.k0, B.k1, x);
+          philox4x32_10(slot, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+        }
+        const uint4* lrow = (const uint4*)(lut + c * LUT_ROW);
+        const uint4 r0 = lrow[0], r1 = lrow[1], r2 = lrow[2];
+        const uint32_t so[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t sw[2], qw[2], acc;
+        sample8(img, code4, lgW, cw, x, so, r2.x, r2.y, sw, qw, acc);
+        const bool st_ok = st.ok && !(dg & 1u);
+        const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
+        const uint32_t qo_ = st_ok ? st.out + (uint32_t)P.L + 3u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, so_, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, qo_, 0, 0);
+        const uint32_t fix = (st.ok && !(dg & 16u)) ? (acc >> 17) & 0xFFu : 0u;
+        const unsigned long long fm = __ballot(fix != 0u);
+        if (fm) {
+          if (nfix + 64u > FIX_CAP) flush_fix();
+          if (fix != 0u) fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(st.r | (fix << 6) | (c << 17), cw);
+          nfix += (uint32_t)__popcll(fm);
+        }
+      };
+      PStage cur = fetch_plain(0);
+      // (two dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
+      for (uint32_t step = 0; step < npsteps; step++) {
+        const PStage nxt = fetch_plain(min(step + 1u, npsteps - 1u));
+        run_plain(cur);
+        cur = nxt;
+      }
+    }
+    // ---- general steps ----
     if (nmain) {
       Stage cur = fetch_step(0);
       // three (dropped) stores: the loop is then entered with the same vector-memory operations behind the first
@@ -1502,7 +1616,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // they merge in L2.  Reads whose last item went to the generic code (0xFFFFFFFF row) get only the
     // separators here; emit_slow_kernel writes the same separator bytes again (benign).
     wave_lds_sync();
-    if (lane < G && t < B.n_slots && !(B.diag & 2u)) {
+    if (lane < G && t < B.n_slots && !(dg & 2u)) {
       const uint4 r0 = meta_rows[lane * 2], r1 = meta_rows[lane * 2 + 1];
       if (r1.x & 0x7FFFFFFFu) {
         const uint32_t np = r1.y & 0xFFFFu, hl = r1.y >> 22;
@@ -1854,7 +1968,7 @@ static EmitLds emit_lds(const DevProfile& P) {
   if (e.fast_TI > 64u) e.fast_TI = 64u;  // longer reads finish in steps of their own
   const size_t img_b = (((size_t)P.bins * P.fast_stride + 3) & ~(size_t)3) * 4;
   e.lds_fast = img_b + (size_t)e.fast_TI * LUT_ROW * 4 + 256 * 4 + meta_b + (size_t)EMIT_WAVES * SLOW_CAP * 4 + (size_t)EMIT_WAVES * FIX_CAP * 8 +
-               (size_t)EMIT_WAVES * 64 + (size_t)EMIT_WAVES * 128 * 2;
+               (size_t)EMIT_WAVES * 64 * 2 + (size_t)EMIT_WAVES * OVF_CAP * 2;
   e.fast_fits = P.kmer == 3 && P.fast_lds != nullptr && e.lds_fast <= kLdsBytes && P.bins < 256;
   return e;
 }
@@ -1902,8 +2016,13 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e.lds_fast);
       hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), e.lds_fast, s, P, B, TIf, inv_TI);
     };
-    if (B.paired) launch_fast(emit_fast_kernel<true>);
-    else launch_fast(emit_fast_kernel<false>);
+    if (B.diag) {  // timing ablations (SG_FDIAG)
+      if (B.paired) launch_fast(emit_fast_kernel<true, true>);
+      else launch_fast(emit_fast_kernel<false, true>);
+    } else {
+      if (B.paired) launch_fast(emit_fast_kernel<true, false>);
+      else launch_fast(emit_fast_kernel<false, false>);
+    }
     if (after_main) (void)hipEventRecord(after_main, s);
     // the queued items through the generic code (reference-order tables)
     const size_t slow_sub = e.sub_lds ? (size_t)e.sub_rows * 16 : 0;
