@@ -54,45 +54,69 @@ def write_config(path, fasta, out_dir, coverage=30, threads=1, profile="Illumina
 
 
 def cpu_baseline(workdir, profile="Illumina_HiSeqXTen.profile"):
-    """Time the reference's CPU thread-pool path on a bounded sample of the same workload, on ALL host cores.
+    """Time the reference's CPU thread-pool path on a bounded sample of the same workload, beside the GPU command line on
+    the same inputs.
 
     Preferred: the UNMODIFIED reference binary built by oracle/Makefile (kind "reference").
     Fallback (binary absent): the oracle restatement (kind "port").  Sample: the C2 chromosome itself (64.4 Mbp at
     30x) on boxes with many cores, a 16 Mbp contig of the same genome on small ones.  The reference's unit of
     parallelism is the <=1 Mbp segment with a barrier per chromosome (Genome.cpp:876-883): 65 work items for this
-    chromosome, whatever `threads` says (on the 256-core GPU box a 256 Mbp contig -- one segment per core -- ran at
-    0.15 M pairs/s against 0.36 M pairs/s on 16 threads: its load and haplotype passes are serial and its writer
-    is one mutex, lib/seqwriter/SeqWriter.cpp:49-54)."""
+    chromosome, whatever `threads` says; its load and haplotype passes are serial and its writer is one mutex
+    (lib/seqwriter/SeqWriter.cpp:49-54), so more threads than ~16 make it SLOWER.  It is therefore run at `threads` = 16
+    and = all host cores; `value` is the better of the two.  `gpu_cli_same_inputs` is the like-for-like number: the whole
+    `simuReads` run of this repo on the same config -- HIP context, FASTA load, FASTQ files written -- on one GPU."""
     from simuscop_amd import synth
     cores = os.cpu_count() or 1
     sample_len = CHR20_LEN if cores >= 32 else 16_000_000
     fa = os.path.join(workdir, "cpu_sample.fa")
-    synth.write_fasta(fa, [("chr20", sample_len)], seed=20)
-    cfg = os.path.join(workdir, "cpu_config.txt")
-    out = os.path.join(workdir, "cpu_out")
-    write_config(cfg, fa, out, threads=cores, profile=profile)
+    synth.write_fasta(fa, [("chr20", sample_len)], seed=20, workers=1)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "simuReads")
-    kind = "reference"
-    if os.path.exists(ref_bin):
-        cmd = [ref_bin, cfg]
-    else:
-        kind = "port"
-        cmd = [os.path.join(ROOT, "oracle", "oracle_cli"), cfg, "--rng", "philox", "--threads", str(cores)]
-    t0 = time.time()
-    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    dt = time.time() - t0
-    if r.returncode != 0:
+    kind = "reference" if os.path.exists(ref_bin) else "port"
+    out = os.path.join(workdir, "cpu_out")
+
+    def count_pairs():
+        lines = 0
+        with open(os.path.join(out, "sim_1.fq"), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                lines += blk.count(b"\n")
+        for fn in os.listdir(out):
+            os.remove(os.path.join(out, fn))
+        return lines // 4
+
+    runs = []
+    for threads in sorted({min(16, cores), cores}):
+        cfg = os.path.join(workdir, f"cpu_config_t{threads}.txt")
+        write_config(cfg, fa, out, threads=threads, profile=profile)
+        cmd = [ref_bin, cfg] if kind == "reference" else [os.path.join(ROOT, "oracle", "oracle_cli"), cfg, "--rng", "philox", "--threads", str(threads)]
+        t0 = time.time()
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        if r.returncode != 0:
+            continue
+        pairs = count_pairs()
+        runs.append({"threads": threads, "value": pairs / dt, "pairs": pairs, "seconds": round(dt, 2)})
+    if not runs:
         return None
-    lines = 0
-    with open(os.path.join(out, "sim_1.fq"), "rb") as f:
-        for blk in iter(lambda: f.read(1 << 24), b""):
-            lines += blk.count(b"\n")
-    pairs = lines // 4
-    for fn in os.listdir(out):
-        os.remove(os.path.join(out, fn))
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "host_cores": f"{cores} of {cores}", "kind": kind,
-            "sample": f"{sample_len} bp contig, {profile[9:-8]} PE 30x insertSize 350, {pairs} pairs in {dt:.1f} s wall "
-                      f"(whole run incl. input load and FASTQ files, threads={cores})"}
+    best = max(runs, key=lambda x: x["value"])
+    res = {"value": best["value"], "unit": "pairs/s", "cores": best["threads"], "host_cores": f"{best['threads']} of {cores}", "kind": kind,
+           "runs": runs,
+           "sample": f"{sample_len} bp contig, {profile[9:-8]} PE 30x insertSize 350, {best['pairs']} pairs in {best['seconds']} s wall "
+                     f"(whole run incl. input load and FASTQ files; the better of threads = {[x['threads'] for x in runs]})"}
+    # the same config through this repo's command line, files written: what a user of the reference would run instead
+    try:
+        cfg = os.path.join(workdir, "cpu_config_t%d.txt" % best["threads"])
+        t0 = time.time()
+        r = subprocess.run([os.path.join(ROOT, "simuscop_amd", "lib", "simuReads"), cfg, "--out", out, "--quiet", "--seed", "1"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        if r.returncode == 0:
+            pairs = count_pairs()
+            res["gpu_cli_same_inputs"] = {"value": pairs / dt, "unit": "pairs/s", "pairs": pairs, "seconds": round(dt, 2),
+                                          "includes": "process start, HIP context, FASTA load, sampling, FASTQ files written (page cache)",
+                                          "ratio_to_cpu_best": (pairs / dt) / best["value"]}
+    except Exception as e:  # noqa: BLE001
+        res["gpu_cli_same_inputs_error"] = repr(e)
+    return res
 
 
 def pmc_evidence():
@@ -108,12 +132,13 @@ def pmc_evidence():
         except Exception:
             continue
         for k, v in d.items():
-            if "emit_fast_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            if k != "_meta" and "emit_fast_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 best = (path, v)
     if not best:
         return None
     path, v = best
-    out = {"source": os.path.relpath(path, ROOT),
+    meta = json.load(open(path)).get("_meta", {})
+    out = {"source": os.path.relpath(path, ROOT), "kernel_ms_profiled": meta.get("emit_fast_kernel_avg_ms"),
            "traffic": (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0}
     if "SQ_INSTS_VALU" in v:
         out["valu"] = v["SQ_INSTS_VALU"]["mean_per_dispatch"]
@@ -170,6 +195,10 @@ def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun and relay its
     output.  Nothing here has touched the GPU yet (no torch import, no engine): the child processes do."""
     import socket
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        # the profiler's preloaded library has initialised the GPU in this process: starting the ranks from here would be the
+        # exec-after-GPU-init the pool forbids (tools/README.md: profile one rank of a multi-GPU run instead)
+        raise SystemExit("bench.py --gpus N cannot start its ranks under rocprofv3: profile one rank (see tools/README.md)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -194,6 +223,9 @@ def main():
     ap.add_argument("--profile", default="xten", choices=sorted(PROFILES),
                     help="sequencing profile of the workload (default: HiSeqXTen, the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--strong-scale", type=float, default=None,
+                    help="c2: size of the genome of the strong-scaling leg (24 contigs, GRCh38 lengths x this; default 1.0, 0.25 on hosts "
+                         "with fewer than 16 cores; 0 = no leg)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -206,6 +238,10 @@ def main():
         return bench_c3.main(args)
     if args.coverage is None:
         args.coverage = 30
+    strong_scale = args.strong_scale if args.strong_scale is not None else (1.0 if (os.cpu_count() or 1) >= 16 else 0.25)
+    if strong_scale:   # the leg's genome: made (by rank 0, on all host cores) before anything here touches the GPU
+        import bench_c3
+        bench_c3.ensure_genome(strong_scale, int(os.environ.get("RANK", "0")))
 
     import torch
     import torch.distributed as dist
@@ -309,6 +345,16 @@ def main():
         main_share = 1.0 - queued_items / max(total_items, 1.0)
         achieved = pairs_per_step * bytes_per_pair * main_share / (emit_ms * 1e-3) / 1e9
         pmc = pmc_evidence() if default_workload else None
+        pmc_stale = None
+        if pmc and pmc.get("kernel_ms_profiled"):
+            # counters of another build say nothing about this one: the profiled launch must have lasted what the live one does
+            # (profiled passes run 3-5 % slower than unprofiled ones; 10 % is a different kernel)
+            if abs(pmc["kernel_ms_profiled"] - emit_ms) > 0.10 * emit_ms:
+                pmc_stale = {"source": pmc["source"], "kernel_ms_profiled": pmc["kernel_ms_profiled"], "kernel_ms_live": emit_ms}
+                pmc = None
+        elif pmc:
+            pmc_stale = {"source": pmc["source"], "reason": "no kernel time recorded with the counters (profiles older than round 3)"}
+            pmc = None
         compute_side = None
         if pmc and "valu" in pmc:
             # VALU issue occupancy of the LIVE launch: wave-instructions of the committed counter pass (the count does not
@@ -343,6 +389,7 @@ def main():
                          "traffic": pmc["traffic"] if pmc else None,
                          "traffic_unit": "bytes per launch",
                          "traffic_source": pmc["source"] if pmc else None,
+                         "traffic_refused_as_stale": pmc_stale,
                          "algorithmic_bytes_per_launch": pairs_per_step * bytes_per_pair * main_share,
                          "kernel": "emit_fast_kernel", "kernel_ms": emit_ms,
                          "items_left_to_emit_slow_kernel": 1.0 - main_share, "emit_slow_kernel_ms": slow_ms,
@@ -360,9 +407,32 @@ def main():
                                       "counts": "pairs whose FASTQ text (plain, or BGZF made on the device) is complete in pinned host "
                                                 "memory, passes drained while the next one is sampled",
                                       "bound": "PCIe Gen5 x16, 63 GB/s (spec)"}
+                # SURVEY 8(d) words the metric at the pinned host buffer: that figure, by name, next to the device-resident `value`
+                hp = out["host_pinned"]
+                out["value_contract"] = {"value": hp["plain"]["value"], "unit": "pairs/s",
+                                         "counts": "pairs whose plain FASTQ text is complete in a pinned host buffer (SURVEY 8(d))",
+                                         "bound": "pcie", "pcie_GBps": hp["plain"]["pcie_GBps"], "pcie_frac_of_63_GBps": hp["plain"]["pcie_GBps"] / 63.0,
+                                         "as_bgzf": hp["gzip"]["value"]}
             except Exception as e:
                 out["host_pinned"] = None
                 out["host_pinned_error"] = repr(e)
+        out["value_device_resident"] = out["value"]
+    sess.close()
+    del sess
+    # ---- strong scaling of ONE genome (BASELINE configs[3]) in the same line: every N, the flag-less run included ----
+    if strong_scale:
+        import bench_c3
+        try:
+            leg = bench_c3.measure("c3", strong_scale, max(1, min(args.steps, 3)), 1, "xten", None, args.backend, rank, local_rank, world)
+        except Exception as e:  # noqa: BLE001 -- the leg must not cost the line
+            leg = {"error": repr(e)}
+        if rank == 0:
+            if isinstance(leg, dict) and "value" in leg:
+                leg = {"value": leg["value"], "unit": leg["unit"], "scaling": "strong", "n_gpus": world, "s_per_run": leg["ms_per_step"] / 1e3,
+                       "runs_timed": leg["steps"], "workload": leg["config"]["workload"], "pairs_per_run": leg["config"]["pairs_per_step"],
+                       "per_rank": leg["per_rank"], "emit_roofline_frac": leg["roofline"]["frac"]}
+            out["strong_c3"] = leg
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(workdir, PROFILES[args.profile][0])
@@ -370,7 +440,6 @@ def main():
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)
         print(json.dumps(out), flush=True)
-    sess.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,7 +77,7 @@ def test_c2_whole_output_md5_equals_oracle_and_bench(oracle_lib, tmp_path):
     assert (md5s[0], sizes[0]) == want["sim_1.fq"] and (md5s[1], sizes[1]) == want["sim_2.fq"]
     # ... and bench.py prints the digest of what it timed
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                        "--no-host-pinned"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-host-pinned", "--strong-scale", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["output_md5"] == md5s and line["output_seed"] == BENCH_SEED

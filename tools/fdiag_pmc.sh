@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 P=${1:-xten}
 for d in 0 1 2 8 16 31; do
   rm -rf gpurun_out/fdpmc
-  SG_FDIAG=$d rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/fdpmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-pinned --no-md5 --profile $P > /dev/null 2>&1
+  SG_FDIAG=$d rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/fdpmc -- python3 bench.py --steps 2 --warmup 1 --strong-scale 0 --no-cpu-baseline --no-host-pinned --no-md5 --profile $P > /dev/null 2>&1
   python3 - "$d" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0, 0.0])
