@@ -156,7 +156,8 @@ def measure(workload, scale, steps, warmup, profile, coverage, backend, rank, lo
     dt = time.perf_counter() - t0
     phases = {k: getattr(last, k) for k in ("t_total", "t_load", "t_engine", "t_reference", "t_haplotypes", "t_plan", "t_sample", "t_hap_device")}
     kernel_ms = {n: float(last.kernel_ms[i]) for i, n in enumerate(simuscop_amd.SG_K_NAMES)}
-    mine = {"rank": rank, "dt": dt, "pairs": frags, "bytes": int(last.fastq_bytes), "phases": phases, "kernel_ms": kernel_ms}
+    mine = {"rank": rank, "dt": dt, "pairs": frags, "bytes": int(last.fastq_bytes), "phases": phases, "kernel_ms": kernel_ms,
+            "work": {"windows": int(last.windows), "segments": int(last.segments), "batches": int(last.batches)}}
     if world > 1:
         allv = [None] * world
         dist.all_gather_object(allv, mine)
@@ -188,5 +189,5 @@ def measure(workload, scale, steps, warmup, profile, coverage, backend, rank, lo
                      "note": "kernel time summed over the chromosomes of the rank with the largest share (its last run)",
                      "algorithmic_bytes_per_pair": bpp, "bytes_note": bench.BYTES_PER_PAIR_FMT},
         "per_rank": [{"rank": v["rank"], "pairs_per_step": v["pairs"] / steps, "s_per_step": v["dt"] / steps,
-                      "phases_last_run_s": v["phases"], "kernel_ms_last_run": v["kernel_ms"]} for v in allv],
+                      "phases_last_run_s": v["phases"], "kernel_ms_last_run": v["kernel_ms"], "work_last_run": v["work"]} for v in allv],
     }

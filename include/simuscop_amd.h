@@ -76,6 +76,15 @@ typedef struct sg_profile_cdf {
   int32_t insert_size;      /* config insertSize (used when isize_cdf == NULL)            */
 } sg_profile_cdf;
 int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* prof);
+/* The same in two steps, so that a host can convert the tables (milliseconds of integer arithmetic: draw counts of every
+ * CDF entry, alias columns) on a worker thread while it streams the reference to the device: sg_profile_prepare touches no
+ * device and no context; sg_load_prepared_profile uploads.  sg_profile_prepare always returns a tables object (free it);
+ * on failure its code is also what sg_load_prepared_profile returns, with the message in sg_last_error. */
+typedef struct sg_profile_tables sg_profile_tables;
+int sg_profile_prepare(const sg_profile_cdf* prof, sg_profile_tables** out);
+const char* sg_profile_tables_error(const sg_profile_tables* tables);
+int sg_load_prepared_profile(sg_ctx* ctx, const sg_profile_tables* tables);
+void sg_profile_tables_free(sg_profile_tables* tables);
 
 /* ---- haplotypes of one (population, chromosome) ------------------------------------------- */
 /* chain h = concatenation over the chromosome's segments, in order, of Segment::segSequences[h]

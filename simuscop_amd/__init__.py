@@ -27,7 +27,7 @@ ENGINE_SYMBOLS = [
     "sg_outputs_last_error", "sg_release_outputs", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
-    "sg_host_free",
+    "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free",
 ]
 
 

@@ -350,6 +350,34 @@ bool Fasta::load_index(const std::string& ref_file, int threads) {
       }
       fclose(f);
       if (rows.empty()) ok = false;
+      // An index newer than the file can still be another file's (cp -p, touch, an edit that keeps the size): every row
+      // is held against the bytes it points at -- a line break before the sequence, a '>' header with the same key in
+      // front of it, and a line break, a header or the end of the file right behind the last base.  Any mismatch: the
+      // header scan below decides, as in the unsharded paths (which never read the .fai).
+      for (size_t i = 0; ok && i < rows.size(); i++) {
+        const FastaContig& r = rows[i];
+        const uint64_t end = r.raw_offset + r.length + (r.length ? (r.length - 1) / r.line_bases : 0) * (uint64_t)(r.line_width - r.line_bases);
+        char hb[2304];
+        const uint64_t back = std::min<uint64_t>(r.raw_offset, sizeof hb);
+        if (back < 2 || pread(fd, hb, back, (off_t)(r.raw_offset - back)) != (ssize_t)back || hb[back - 1] != '\n') { ok = false; break; }
+        int64_t h = (int64_t)back - 2;   // start of the header line: the byte after the previous line break
+        while (h >= 0 && hb[h] != '\n') h--;
+        if (h < 0 && back < r.raw_offset) { ok = false; break; }   // a header longer than the buffer: not an index of this file
+        const char* line = hb + h + 1;
+        if (*line != '>') { ok = false; break; }
+        std::string name(line + 1, (size_t)((hb + back - 1) - (line + 1)));
+        if (!name.empty() && name.back() == '\r') name.pop_back();
+        name = name.substr(0, name.find_first_of(" \t"));
+        if (abbr_of_chr(name) != keys[i]) { ok = false; break; }
+        if (end < size) {
+          char c = 0;
+          if (pread(fd, &c, 1, (off_t)end) != 1 || (c != '\n' && c != '\r' && c != '>')) { ok = false; break; }
+        }
+        if (r.length) {   // the last base is a base
+          char c = 0;
+          if (pread(fd, &c, 1, (off_t)(end - 1)) != 1 || c == '\n' || c == '\r' || c == '>') { ok = false; break; }
+        }
+      }
       if (!ok) { keys.clear(); rows.clear(); }
     }
   }

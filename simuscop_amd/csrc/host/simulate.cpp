@@ -640,6 +640,24 @@ struct Driver {
     genome.shard_rank = opt.shard_rank;
     genome.shard_world = opt.shard_world;
     genome.shard_contigs = opt.shard_contigs != 0 && opt.shard_world > 1;
+    // The profile -- parsing its text (Profile::load / normParas / initCDFs), converting every CDF row into the engine's
+    // integer tables (sg_profile_prepare: no device involved) -- on a worker thread while this one streams the reference
+    // to the device: ~10 ms of work that every rank of a sharded run would otherwise repeat on its critical path.
+    sg_profile_tables* tables = nullptr;
+    std::string prof_err;
+    int prof_exit = 1;
+    const std::string prof_path = cfg.str["profile"];   // (the worker must not touch the config maps: operator[] inserts)
+    const bool prof_paired = cfg.paired();
+    const int prof_isize = (int)cfg.num["insertSize"];
+    std::thread prof_thread([&]() {
+      try {
+        prof.train(prof_path, prof_paired, prof_isize);
+        sg_profile_cdf view = prof.view();
+        sg_profile_prepare(&view, &tables);
+      } catch (const Error& e) { prof_err = e.what(); prof_exit = e.exit_code ? e.exit_code : 1; }
+      catch (const std::exception& e) { prof_err = e.what(); }
+    });
+    struct Joiner { std::thread& t; sg_profile_tables*& T; ~Joiner() { if (t.joinable()) t.join(); if (T) sg_profile_tables_free(T); T = nullptr; } } joiner{prof_thread, tables};
     genome.load_data();
     st.t_reference = genome.t_reference;
     const std::string out_dir = (opt.output_dir && opt.output_dir[0]) ? opt.output_dir : cfg.str["output"];
@@ -647,10 +665,10 @@ struct Driver {
       for (size_t i = 1; i <= out_dir.size(); i++)
         if (i == out_dir.size() || out_dir[i] == '/') mkdir(out_dir.substr(0, i).c_str(), 0755);
     }
-    prof.train(cfg.str["profile"], cfg.paired(), (int)cfg.num["insertSize"]);
+    prof_thread.join();
+    if (!prof_err.empty()) throw Error(prof_err, prof_exit);
     log("profile was loaded from file " + cfg.str["profile"] + "\n");
-    sg_profile_cdf view = prof.view();
-    eng.check(sg_load_profile(eng.ctx, &view), "sg_load_profile");
+    eng.check(sg_load_prepared_profile(eng.ctx, tables), "sg_load_profile");
     genome.generate_segments();
     st.t_load = since(t0);
     st.planned_reads = (uint64_t)(genome.target_length() * cfg.num["coverage"] / prof.read_length);

@@ -335,20 +335,34 @@ int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
-  if (!ctx || !pr) return SG_ERR_INVALID;
-  SG_HIP(hipSetDevice(ctx->device));
-  if (pr->n_bases != 4) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: only 4-letter base alphabets are supported");
-  if (pr->kmer < 1 || pr->kmer > 6) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: kmer must be in 1..6");
-  if (pr->bins < 1 || pr->read_length < 1 || pr->read_length > 30000) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: bad bins/read_length");
+// The tables of a profile as the engine wants them, made on the host (sg_profile_prepare: no device, any thread) and
+// uploaded by sg_load_prepared_profile.  Offsets are in 32-bit words into `tab`.
+struct sg_profile_tables {
+  std::vector<uint32_t> tab;
+  size_t sub_off = 0, sub_rows = 0, alias_off = 0, fast_lds_off = 0, fast_sub_off = 0, fast_alias_off = 0, ins_off = 0, del_off = 0, isz_off = 0,
+         gap_off = 0;
+  uint32_t lgW = 0, fast_stride = 0, ins_lg = 0, del_lg = 0, isz_lg = 0, inv_remap = 0, remap = 0, packed = 0;
+  bool has2 = false, has_isz = false;
+  uint64_t evA = 0, evB = 0;
+  int kmer = 0, bins = 0, read_length = 0, min_qual = 0, isize_min = 0, insert_size = 0, n_isize = 0;
+  int rc = SG_OK;
+  std::string err;
+  int fail(int code, const std::string& msg) { rc = code; err = msg; return code; }
+};
+
+static int build_tables(const sg_profile_cdf* pr, sg_profile_tables& T) {
+  if (!pr) return T.fail(SG_ERR_INVALID, "sg_profile_prepare: null profile");
+  if (pr->n_bases != 4) return T.fail(SG_ERR_UNSUPPORTED, "sg_load_profile: only 4-letter base alphabets are supported");
+  if (pr->kmer < 1 || pr->kmer > 6) return T.fail(SG_ERR_UNSUPPORTED, "sg_load_profile: kmer must be in 1..6");
+  if (pr->bins < 1 || pr->read_length < 1 || pr->read_length > 30000) return T.fail(SG_ERR_INVALID, "sg_load_profile: bad bins/read_length");
   {  // the kernels compute bin = i*bins/n' with a 32-bit reciprocal: exact while i*bins*n' < 2^32
     const uint64_t npmax = (uint64_t)pr->read_length + (uint64_t)SG_MAX_EVENTS * (uint64_t)(pr->n_ins > 0 ? pr->n_ins : 1);
     if (npmax > 0xFFFF || npmax * (uint64_t)pr->bins * npmax >= (1ull << 32))
-      return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: read_length * bins too large for the 32-bit bin arithmetic");
+      return T.fail(SG_ERR_UNSUPPORTED, "sg_load_profile: read_length * bins too large for the 32-bit bin arithmetic");
   }
-  if (pr->n_qual < 1 || pr->n_qual > 128) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: n_qual must be in 1..128 (quality symbols are 7-bit fields)");
+  if (pr->n_qual < 1 || pr->n_qual > 128) return T.fail(SG_ERR_INVALID, "sg_load_profile: n_qual must be in 1..128 (quality symbols are 7-bit fields)");
   if (!pr->subs_cdf1 || !pr->qual_cdf || !pr->ins_cdf || !pr->del_cdf || pr->n_ins < 1 || pr->n_del < 1)
-    return ctx->fail(SG_ERR_INVALID, "sg_load_profile: missing table");
+    return T.fail(SG_ERR_INVALID, "sg_load_profile: missing table");
   // base alphabet must be a permutation of ACGT (the kernels classify haplotype bytes by value)
   uint32_t remap = 0, packed = 0;
   {
@@ -356,7 +370,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     for (int n = 0; n < 4; n++) {
       int code = -1;
       for (int k = 0; k < 4; k++) if (pr->bases[k] == nat[n]) code = k;
-      if (code < 0) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: bases must be a permutation of ACGT");
+      if (code < 0) return T.fail(SG_ERR_UNSUPPORTED, "sg_load_profile: bases must be a permutation of ACGT");
       remap |= (uint32_t)code << (2 * n);
     }
     for (int k = 0; k < 4; k++) packed |= (uint32_t)(uint8_t)pr->bases[k] << (8 * k);
@@ -380,7 +394,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
       off += p4;
     }
   }
-  std::vector<uint32_t> tab;
+  std::vector<uint32_t>& tab = T.tab;
   // substitution rows, identity first (sg_tables.h): {D0, D1, D2, j0 | o0<<2 | o1<<4 | o2<<6 | o3<<8}, o in profile codes
   const size_t sub_rows = (size_t)kmer_count * bins;
   const size_t sub_off = 0;
@@ -412,7 +426,7 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   try {
     for (size_t r = 0; r < qrows; r++) arows[r] = sg::build_alias_row(qmass[r], lgW);
   } catch (const std::exception& e) {
-    return ctx->fail(SG_ERR_INVALID, std::string("sg_load_profile: ") + e.what());
+    return T.fail(SG_ERR_INVALID, std::string("sg_load_profile: ") + e.what());
   }
   while (tab.size() % 4) tab.push_back(0);
   const size_t alias_off = tab.size();
@@ -443,10 +457,10 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   // `p < delRate/(1-insertRate)`, p = x/2^32 (Profile.cpp:1560-1570).  cI, cD = the numbers of 32-bit draws that pass;
   // a position is a candidate with probability evB / 2^64, evB = cI 2^32 + (2^32 - cI) cD, an insertion with evA / evB,
   // evA = cI 2^32.  gap[k] = floor(gap[k-1] * gap[1] / 2^64), gap[1] = 2^64 - evB: P(no candidate in k positions).
-  if (pr->insert_rate < 0) return ctx->fail(SG_ERR_INVALID, "sg_load_profile: negative insert rate");
+  if (pr->insert_rate < 0) return T.fail(SG_ERR_INVALID, "sg_load_profile: negative insert rate");
   const uint64_t ci = sg::count_unit_le(pr->insert_rate);
   const uint64_t cd = sg::count_unit_lt(pr->del_rate / (1 - pr->insert_rate));
-  if (ci >= (1ull << 31) || cd >= (1ull << 31)) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_load_profile: sequencing indel rate >= 0.5");
+  if (ci >= (1ull << 31) || cd >= (1ull << 31)) return T.fail(SG_ERR_UNSUPPORTED, "sg_load_profile: sequencing indel rate >= 0.5");
   const uint64_t evA = ci << 32, evB = evA + ((1ull << 32) - ci) * cd;
   while (tab.size() % 4) tab.push_back(0);
   const size_t gap_off = tab.size();
@@ -540,41 +554,75 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
     while (tab.size() % 4) tab.push_back(0);
   }
 
+  T.sub_off = sub_off; T.sub_rows = sub_rows; T.has2 = has2; T.alias_off = alias_off; T.lgW = lgW;
+  T.fast_lds_off = fast_lds_off; T.fast_sub_off = fast_sub_off; T.fast_alias_off = fast_alias_off; T.fast_stride = fast_stride;
+  T.ins_off = ins_off; T.ins_lg = ins_lg; T.del_off = del_off; T.del_lg = del_lg; T.isz_off = isz_off; T.isz_lg = isz_lg; T.has_isz = has_isz;
+  T.inv_remap = inv_remap; T.remap = remap; T.packed = packed; T.evA = evA; T.evB = evB; T.gap_off = gap_off;
+  T.kmer = pr->kmer; T.bins = bins; T.read_length = pr->read_length; T.min_qual = pr->min_qual;
+  T.isize_min = pr->isize_min; T.insert_size = pr->insert_size; T.n_isize = pr->n_isize;
+  return SG_OK;
+}
+
+int sg_profile_prepare(const sg_profile_cdf* pr, sg_profile_tables** out) {
+  if (!out) return SG_ERR_INVALID;
+  sg_profile_tables* T = new sg_profile_tables();
+  *out = T;
+  T->rc = build_tables(pr, *T);
+  return T->rc;
+}
+const char* sg_profile_tables_error(const sg_profile_tables* T) { return T ? T->err.c_str() : "null tables"; }
+void sg_profile_tables_free(sg_profile_tables* T) { delete T; }
+
+int sg_load_prepared_profile(sg_ctx* ctx, const sg_profile_tables* Tp) {
+  if (!ctx || !Tp) return SG_ERR_INVALID;
+  const sg_profile_tables& T = *Tp;
+  if (T.rc != SG_OK) return ctx->fail(T.rc, T.err);
+  SG_HIP(hipSetDevice(ctx->device));
+  const std::vector<uint32_t>& tab = T.tab;
   SG_ENSURE(ctx->tab, tab.size() * 4);
   SG_HIP(hipMemcpyAsync(ctx->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   SG_HIP(hipStreamSynchronize(ctx->stream));
 
   sg::DevProfile& P = ctx->P;
   const uint32_t* base = ctx->tab.as<uint32_t>();
-  P.sub = (const uint4*)(base + sub_off);
-  P.sub_mate_rows = has2 ? (uint32_t)sub_rows : 0u;
-  P.alias = (const uint2*)(base + alias_off);
-  P.lgW = lgW;
-  P.fast_lds = pr->kmer == 3 ? base + fast_lds_off : nullptr;
-  P.fast_mate_words = has2 ? (uint32_t)bins * fast_stride : 0u;
-  P.fast_stride = fast_stride;
-  P.fast_sub = pr->kmer == 3 ? (const uint4*)(base + fast_sub_off) : nullptr;
-  P.fast_alias = pr->kmer == 3 ? (const uint2*)(base + fast_alias_off) : nullptr;
-  P.ins_row = base + ins_off; P.ins_lg = ins_lg;
-  P.del_row = base + del_off; P.del_lg = del_lg;
-  P.isz_row = has_isz ? base + isz_off : nullptr; P.isz_lg = isz_lg;
-  P.inv_remap_packed = inv_remap;
-  P.isz_min = pr->isize_min;
-  P.fixed_isz = pr->insert_size;
-  P.isz_lo = has_isz ? pr->isize_min : pr->insert_size;
-  P.isz_hi = has_isz ? pr->isize_min + pr->n_isize - 1 : pr->insert_size;
-  P.evA = evA; P.evB = evB;
-  P.gap_row = (const uint64_t*)(base + gap_off);
-  P.L = pr->read_length; P.bins = bins; P.kmer = pr->kmer; P.min_qual = pr->min_qual;
-  P.remap_packed = remap; P.bases_packed = packed;
+  P.sub = (const uint4*)(base + T.sub_off);
+  P.sub_mate_rows = T.has2 ? (uint32_t)T.sub_rows : 0u;
+  P.alias = (const uint2*)(base + T.alias_off);
+  P.lgW = T.lgW;
+  P.fast_lds = T.kmer == 3 ? base + T.fast_lds_off : nullptr;
+  P.fast_mate_words = T.has2 ? (uint32_t)T.bins * T.fast_stride : 0u;
+  P.fast_stride = T.fast_stride;
+  P.fast_sub = T.kmer == 3 ? (const uint4*)(base + T.fast_sub_off) : nullptr;
+  P.fast_alias = T.kmer == 3 ? (const uint2*)(base + T.fast_alias_off) : nullptr;
+  P.ins_row = base + T.ins_off; P.ins_lg = T.ins_lg;
+  P.del_row = base + T.del_off; P.del_lg = T.del_lg;
+  P.isz_row = T.has_isz ? base + T.isz_off : nullptr; P.isz_lg = T.isz_lg;
+  P.inv_remap_packed = T.inv_remap;
+  P.isz_min = T.isize_min;
+  P.fixed_isz = T.insert_size;
+  P.isz_lo = T.has_isz ? T.isize_min : T.insert_size;
+  P.isz_hi = T.has_isz ? T.isize_min + T.n_isize - 1 : T.insert_size;
+  P.evA = T.evA; P.evB = T.evB;
+  P.gap_row = (const uint64_t*)(base + T.gap_off);
+  P.L = T.read_length; P.bins = T.bins; P.kmer = T.kmer; P.min_qual = T.min_qual;
+  P.remap_packed = T.remap; P.bases_packed = T.packed;
   {
     uint32_t off = 0, p = 1;
     for (int m = 0; m < 8; m++) P.kmer_off[m] = 0;
-    for (int m = 1; m <= pr->kmer; m++) { P.kmer_off[m] = off; p *= 4; off += p; }
+    for (int m = 1; m <= T.kmer; m++) { P.kmer_off[m] = off; p *= 4; off += p; }
   }
   ctx->have_profile = true;
   ctx->have_plan = false;
   return SG_OK;
+}
+
+int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
+  if (!ctx || !pr) return SG_ERR_INVALID;
+  sg_profile_tables* T = nullptr;
+  sg_profile_prepare(pr, &T);
+  const int rc = sg_load_prepared_profile(ctx, T);
+  sg_profile_tables_free(T);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1112,8 +1160,12 @@ static int finish_pass(sg_ctx* ctx) {
     sg::DevBatch& B = ctx->B;
     SG_ENSURE(ctx->out1, ctx->host_totals[0] + 64);
     if (B.paired) SG_ENSURE(ctx->out2, ctx->host_totals[1] + 64);
-    SG_HIP(hipMemsetAsync(B.totals + 3, 0, 8, ctx->stream));
-    if (int rc = launch_text(ctx, false)) return rc;
+    // what the aborted launch left behind: the flags, the slow-queue counts (a mate whose text did fit has appended its
+    // items already) and the read-group counters of both emit kernels (exhausted by that mate); the record offsets' segment
+    // bases and the sizes stay
+    SG_HIP(hipMemsetAsync(B.totals + 3, 0, 2 * 8, ctx->stream));
+    SG_HIP(hipMemsetAsync((uint8_t*)B.totals + 128, 0, sg::kTotalsSegBase - 128, ctx->stream));
+    if (int rc = launch_text(ctx, ctx->profiling)) return rc;   // (the kernel times are then those of the launch that counted)
     sg::launch_mail(B.totals, ctx->mail, ctx->stream);
     SG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->host_flags[0] = ctx->mail[3];
@@ -1213,6 +1265,8 @@ int sg_host_free(sg_ctx* ctx, void* host_ptr) {
 int sg_device_output(sg_ctx* ctx, void** dev_r1, void** dev_r2) {
   if (!ctx) return SG_ERR_INVALID;
   if (!ctx->sampled) return ctx->fail(SG_ERR_INVALID, "sg_device_output: call sg_sample first");
+  SG_HIP(hipSetDevice(ctx->device));
+  if (int rc = finish_pass(ctx)) return rc;   // a pass queued without its size may still move to larger buffers
   if (dev_r1) *dev_r1 = ctx->out1.p;
   if (dev_r2) *dev_r2 = ctx->B.paired ? ctx->out2.p : nullptr;
   return SG_OK;

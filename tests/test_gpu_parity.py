@@ -203,3 +203,66 @@ def test_bench_strong_scaling_modes(workload):
     want = sum(length for _, length in synth.grch38_contigs(scale)) * coverage / 151 / 2
     assert abs(pairs - want) < 0.02 * want      # ceil(n/2) pairs per window: a little above reads / 2
     assert all(r["pairs_per_step"] > 0 for r in two["per_rank"])
+
+
+def test_sharded_ranks_do_only_their_own_share():
+    """Strong scaling is by construction: with N ranks owning whole chromosomes, what a rank ingests, scans, plans and samples
+    is its chromosomes' share of the genome and nothing else.  bench.py --workload c3 on four ranks sharing the device (gloo
+    rehearsal of the RCCL exchange) against one rank: the ranks' windows, segments and pairs add up to the one-rank run's,
+    each rank's part follows its share of the bases."""
+    import json
+    import sys
+    from simuscop_amd import synth
+    scale = 0.25
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--scale", str(scale), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    lines = []
+    for extra, env in (([], {}), (["--gpus", "4", "--backend", "gloo"], {"BENCH_SAME_DEVICE": "1"})):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]))
+    one, four = lines
+    one_r = one["per_rank"][0]
+    lens = [length for _, length in synth.grch38_contigs(scale)]
+    import ctypes
+    import simuscop_amd
+    host = simuscop_amd.load_host()
+    owner = (ctypes.c_int32 * len(lens))()
+    host.simu_assign_contigs((ctypes.c_uint64 * len(lens))(*lens), len(lens), 4, owner)
+    share = [sum(l for l, o in zip(lens, owner) if o == r) / sum(lens) for r in range(4)]
+    assert max(share) < 0.27 and min(share) > 0.23
+    for key in ("windows", "segments", "batches"):
+        assert sum(v["work_last_run"][key] for v in four["per_rank"]) == one_r["work_last_run"][key], key
+    assert abs(sum(v["pairs_per_step"] for v in four["per_rank"]) - one_r["pairs_per_step"]) < 1e-6 * one_r["pairs_per_step"]
+    for v in four["per_rank"]:
+        s_r = share[v["rank"]]
+        assert abs(v["work_last_run"]["windows"] / one_r["work_last_run"]["windows"] - s_r) < 0.01, v
+        assert abs(v["pairs_per_step"] / one_r["pairs_per_step"] - s_r) < 0.02, v
+        # (phase TIMES are not held to a bound here: the four processes share one device, one PCIe link and one page cache;
+        # what a rank does -- windows, segments, batches, pairs -- is what is checked)
+
+
+def test_a_stale_fasta_index_is_not_trusted(tmp_path):
+    """--shard-contigs reads a rank's contigs through the .fai when one is there.  An index that is newer than the file but
+    belongs to another genome (same size, other line breaks / another contig order) must not be believed: the header scan
+    takes over and the records are those of the one-GPU run."""
+    from simuscop_amd import synth
+    cfg = cases.build_case("wgs_pe_variants", str(tmp_path))
+    one = str(tmp_path / "one")
+    _run_gpu(cfg, one)
+    fa = os.path.join(str(tmp_path), "ref.fa")
+    contigs = [("chr20", 3200000), ("chr21", 1234567), ("chrM", 777)]
+    synth.write_fai(fa, contigs)                       # the true index ...
+    rows = open(fa + ".fai").read().split("\n")
+    f0, f1 = rows[0].split("\t"), rows[1].split("\t")
+    # ... bent: the first two contigs trade 10 kbp (offsets stay inside the file, every range ends inside it)
+    f0[1] = str(int(f0[1]) - 10020)
+    f1[2] = str(int(f1[2]) - 10020 - 10020 // 60)
+    f1[1] = str(int(f1[1]) + 10020)
+    open(fa + ".fai", "w").write("\n".join(["\t".join(f0), "\t".join(f1)] + rows[2:]))
+    env = dict(os.environ, SIMUSCOP_SAME_DEVICE="1")
+    d = str(tmp_path / "ranks")
+    r = subprocess.run([SIMU, cfg, "--seed", str(SEED), "--out", d, "--quiet", "--gpus", "3", "--shard-contigs"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for f in _files(one):
+        assert sorted(_records(open(os.path.join(d, f), "rb").read())) == sorted(_records(open(os.path.join(one, f), "rb").read())), f
