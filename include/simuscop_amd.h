@@ -307,6 +307,24 @@ int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
  * their queue overflowed so that the whole batch was emitted again by the generic kernel.  Results
  * are identical either way (Profile::predict, Profile.cpp:1520-1650 has one code path).          */
 int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
+/* ---- profile training, counting half ---------------------------------------------
+ * What Profile::processRead (lib/profile/Profile.cpp:228-510) adds to its count matrices for lines of `samtools view`
+ * text (the reference reads them through popen, Profile.cpp:1448-1462): the filters of :262-288, the CIGAR walk with its
+ * insertion / deletion length counts (:294-388; only a single nM reaches the counters), subsDist1 / subsDist2 / kmersDist
+ * (:405-441), iSizeDist (:443-450), qualityDist (:452-480).  The reference bases come from the contigs committed with
+ * sg_reference_commit (upper-cased as Genome.cpp:529); `contig_keys` names them in that order, chr / chrom prefix
+ * stripped.  Not included: Profile::countGC (:512-703, sequential over the file; it also gates which reads count) and
+ * known variants (the VCF side); reads overhanging their contig's end are skipped and counted in skipped_overhang.
+ * Arrays are the caller's: subs1 / subs2 [kmer_count][bins][4], kmers [bins][kmer_count], quality [16][bins][94],
+ * isize [n_isize].  Bases must be a permutation of ACGT, kmer 1..6.                                                  */
+typedef struct sg_train_counts {
+  uint64_t *subs1, *subs2, *kmers, *quality, *isize;
+  uint64_t ins_len[256], del_len[256];
+  uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, skipped_overhang;
+} sg_train_counts;
+int sg_train_count(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes, const char* const* contig_keys, uint32_t n_contigs,
+                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, sg_train_counts* out);
+
 /* Which emit kernel the loaded profile gets (after sg_load_profile): 0 generic (tables that do not fit
  * LDS, k-mer sizes other than 3), 1 straight-line kernel (table image in LDS). */
 int sg_emit_variant(sg_ctx* ctx);

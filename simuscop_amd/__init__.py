@@ -27,8 +27,17 @@ ENGINE_SYMBOLS = [
     "sg_outputs_last_error", "sg_release_outputs", "sg_plan", "sg_sample", "sg_result", "sg_fetch", "sg_device_output",
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
-    "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free",
+    "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free", "sg_train_count",
 ]
+
+
+class SgTrainCounts(C.Structure):
+    """sg_train_counts / orc_train_counts (same layout): caller-allocated count arrays + scalar counters."""
+    _fields_ = [("subs1", C.POINTER(C.c_uint64)), ("subs2", C.POINTER(C.c_uint64)), ("kmers", C.POINTER(C.c_uint64)),
+                ("quality", C.POINTER(C.c_uint64)), ("isize", C.POINTER(C.c_uint64)),
+                ("ins_len", C.c_uint64 * 256), ("del_len", C.c_uint64 * 256),
+                ("lines", C.c_uint64), ("reads_counted", C.c_uint64), ("cigar_chars", C.c_uint64), ("insert_events", C.c_uint64),
+                ("delete_events", C.c_uint64), ("isize_overflow", C.c_uint64), ("skipped_overhang", C.c_uint64)]
 
 
 class SgProfileCdf(C.Structure):
@@ -120,6 +129,8 @@ def load_engine():
     lib.sg_sync.argtypes = [vp]
     lib.sg_reference_scan.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.sg_reference_commit.argtypes = [vp, C.POINTER(SgContig), C.c_uint32]
+    lib.sg_train_count.argtypes = [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_int32, C.c_int32,
+                                   C.c_uint32, C.POINTER(SgTrainCounts)]
     lib.sg_build_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(SgHapPiece), C.c_uint64,
                                         C.c_char_p, C.c_uint64, C.POINTER(SgHapPatch), C.c_uint64]
     lib.sg_haplotype_codes.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p]

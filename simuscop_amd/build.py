@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 INCLUDE = os.path.join(ROOT, "include")
 
-ENGINE_SRCS = ["sg_kernels.hip", "sg_haplotypes.hip", "sg_deflate.hip", "sg_api.cpp", "sg_tables.cpp", "sg_deflate.cpp"]
+ENGINE_SRCS = ["sg_kernels.hip", "sg_haplotypes.hip", "sg_deflate.hip", "sg_train.hip", "sg_api.cpp", "sg_tables.cpp", "sg_deflate.cpp"]
 HOST_SRCS = ["host/config.cpp", "host/profile.cpp", "host/fasta.cpp", "host/variants.cpp", "host/genome.cpp",
              "host/simulate.cpp"]
 CLI_SRCS = ["host/main.cpp"]

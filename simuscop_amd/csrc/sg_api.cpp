@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "sg_deflate.h"
+#include "sg_train.h"
 #include "sg_device.h"
 #include "sg_tables.h"
 
@@ -623,6 +624,130 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
   const int rc = sg_load_prepared_profile(ctx, T);
   sg_profile_tables_free(T);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profile training, counting half (sg_train.hip)
+// ------------------------------------------------------------------------------------------------
+int sg_train_count(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes, const char* const* contig_keys, uint32_t n_contigs,
+                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, sg_train_counts* out) {
+  if (!ctx || !out || (sam_bytes && !sam_text) || !bases || (n_contigs && !contig_keys)) return SG_ERR_INVALID;
+  if (ctx->ref_contigs.empty() || n_contigs != ctx->ref_contigs.size())
+    return ctx->fail(SG_ERR_INVALID, "sg_train_count: name the contigs of sg_reference_commit, in its order");
+  if (strlen(bases) != 4 || kmer < 1 || kmer > 6 || bins < 1 || n_isize < 1)
+    return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: bases must hold four letters, kmer 1..6, bins >= 1");
+  uint32_t remap = 0;
+  {
+    const char nat[4] = {'A', 'C', 'T', 'G'};
+    for (int n = 0; n < 4; n++) {
+      int code = -1;
+      for (int k = 0; k < 4; k++) if (bases[k] == nat[n]) code = k;
+      if (code < 0) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: bases must be a permutation of ACGT");
+      remap |= (uint32_t)code << (2 * n);
+    }
+  }
+  SG_HIP(hipSetDevice(ctx->device));
+  // line starts (empty lines dropped); a last line without a line break gets one in the device copy
+  std::vector<uint64_t> off;
+  const bool open_end = sam_bytes && sam_text[sam_bytes - 1] != '\n';
+  for (uint64_t a = 0; a < sam_bytes;) {
+    const char* nl = (const char*)memchr(sam_text + a, '\n', sam_bytes - a);
+    const uint64_t e = nl ? (uint64_t)(nl - sam_text) : sam_bytes;
+    if (e > a) off.push_back(a);
+    a = e + 1;
+  }
+  const uint64_t n_lines = off.size();
+  // (line_off[i + 1] - 1 must be line i's break: offsets of dropped empty lines would break that, so lines are re-based)
+  std::vector<uint64_t> ends(n_lines + 1, 0);
+  std::string packed;
+  if (n_lines) {
+    packed.reserve(sam_bytes + 1);
+    for (uint64_t i = 0; i < n_lines; i++) {
+      const char* b = sam_text + off[i];
+      const char* nl = (const char*)memchr(b, '\n', sam_bytes - off[i]);
+      const uint64_t len = nl ? (uint64_t)(nl - b) : sam_bytes - off[i];
+      ends[i] = packed.size();
+      packed.append(b, len);
+      packed.push_back('\n');
+    }
+    ends[n_lines] = packed.size();
+  }
+  (void)open_end;
+  uint32_t kc = 0, koff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    uint32_t p4 = 1;
+    for (int m = 1; m <= kmer; m++) { koff[m] = kc; p4 *= 4; kc += p4; }
+  }
+  const size_t subs_n = (size_t)kc * bins * 4, kmers_n = (size_t)bins * kc, qual_n = (size_t)16 * bins * 94;
+  const size_t counters = 2 * subs_n + kmers_n + qual_n + n_isize + sg::kTrainScalars;
+  DevBuf d_text, d_off, d_keys, d_contigs, d_reads, d_counts, d_flags;
+  struct Free { DevBuf* b[7]; ~Free() { for (DevBuf* x : b) x->release(); } } freer{{&d_text, &d_off, &d_keys, &d_contigs, &d_reads, &d_counts, &d_flags}};
+  SG_ENSURE(d_text, packed.size() + 64);
+  SG_ENSURE(d_off, (n_lines + 1) * 8);
+  SG_ENSURE(d_keys, (size_t)n_contigs * sg::kTrainKeyBytes + 64);
+  SG_ENSURE(d_contigs, (size_t)n_contigs * sizeof(sg::TrainContig) + 64);
+  SG_ENSURE(d_reads, (n_lines + 1) * sizeof(sg::TrainRead));
+  SG_ENSURE(d_counts, counters * 8);
+  SG_ENSURE(d_flags, 64);
+  std::vector<char> keys((size_t)n_contigs * sg::kTrainKeyBytes, 0);
+  std::vector<sg::TrainContig> tc(n_contigs);
+  for (uint32_t c = 0; c < n_contigs; c++) {
+    if (!contig_keys[c] || strlen(contig_keys[c]) >= sg::kTrainKeyBytes) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: contig name too long");
+    strcpy(&keys[(size_t)c * sg::kTrainKeyBytes], contig_keys[c]);
+    tc[c] = sg::TrainContig{ctx->ref_contigs[c].code_off, ctx->ref_contigs[c].length};
+  }
+  hipStream_t s = ctx->stream;
+  if (!packed.empty()) SG_HIP(hipMemcpyAsync(d_text.p, packed.data(), packed.size(), hipMemcpyHostToDevice, s));
+  SG_HIP(hipMemcpyAsync(d_off.p, ends.data(), (n_lines + 1) * 8, hipMemcpyHostToDevice, s));
+  if (n_contigs) {
+    SG_HIP(hipMemcpyAsync(d_keys.p, keys.data(), keys.size(), hipMemcpyHostToDevice, s));
+    SG_HIP(hipMemcpyAsync(d_contigs.p, tc.data(), tc.size() * sizeof(sg::TrainContig), hipMemcpyHostToDevice, s));
+  }
+  SG_HIP(hipMemsetAsync(d_counts.p, 0, counters * 8, s));
+  SG_HIP(hipMemsetAsync(d_flags.p, 0, 64, s));
+  sg::TrainJob J;
+  memset(&J, 0, sizeof J);
+  J.text = d_text.as<char>();
+  J.line_off = d_off.as<uint64_t>();
+  J.n_lines = n_lines;
+  J.keys = d_keys.as<char>();
+  J.contigs = d_contigs.as<sg::TrainContig>();
+  J.n_contigs = n_contigs;
+  J.ref_codes = ctx->ref_codes.as<uint8_t>();
+  memcpy(J.bases, bases, 4);
+  J.remap = remap;
+  J.kmer = (uint32_t)kmer; J.bins = (uint32_t)bins; J.kmer_count = kc; J.n_isize = n_isize;
+  for (int m = 0; m < 8; m++) J.kmer_off[m] = koff[m];
+  J.reads = d_reads.as<sg::TrainRead>();
+  unsigned long long* c0 = d_counts.as<unsigned long long>();
+  J.subs1 = c0; J.subs2 = c0 + subs_n; J.kmers = c0 + 2 * subs_n; J.quality = J.kmers + kmers_n; J.isize = J.quality + qual_n;
+  J.scalars = J.isize + n_isize;
+  J.flags = d_flags.as<uint32_t>();
+  sg::launch_train(J, s);
+  SG_HIP(hipGetLastError());
+  std::vector<uint64_t> host(counters);
+  uint32_t flags = 0;
+  SG_HIP(hipMemcpyAsync(host.data(), d_counts.p, counters * 8, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  if (flags & 1u) return ctx->fail(SG_ERR_INVALID, "sg_train_count: malformed read, there should be 11 mandatory fields");   // Profile.cpp:246-251
+  const uint64_t* h = host.data();
+  memcpy(out->subs1, h, subs_n * 8);
+  memcpy(out->subs2, h + subs_n, subs_n * 8);
+  memcpy(out->kmers, h + 2 * subs_n, kmers_n * 8);
+  memcpy(out->quality, h + 2 * subs_n + kmers_n, qual_n * 8);
+  memcpy(out->isize, h + 2 * subs_n + kmers_n + qual_n, (size_t)n_isize * 8);
+  const uint64_t* sc = h + 2 * subs_n + kmers_n + qual_n + n_isize;
+  memcpy(out->ins_len, sc + sg::kTrainInsLen, 256 * 8);
+  memcpy(out->del_len, sc + sg::kTrainDelLen, 256 * 8);
+  out->lines = n_lines;
+  out->reads_counted = sc[sg::kTrainReads];
+  out->cigar_chars = sc[sg::kTrainCigarChars];
+  out->insert_events = sc[sg::kTrainInsEvents];
+  out->delete_events = sc[sg::kTrainDelEvents];
+  out->isize_overflow = sc[sg::kTrainIsizeOverflow];
+  out->skipped_overhang = sc[sg::kTrainOverhang];
+  return SG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

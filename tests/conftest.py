@@ -69,7 +69,7 @@ def oracle_lib():
     import ctypes
     odir = os.path.join(ROOT, "oracle")
     so = os.path.join(odir, "liboracle.so")
-    srcs = [os.path.join(odir, f) for f in ("oracle.cpp", "oracle.h", "philox.h")]
+    srcs = [os.path.join(odir, f) for f in ("oracle.cpp", "train_oracle.cpp", "oracle.h", "philox.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", odir, "liboracle.so", "oracle_cli"], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)

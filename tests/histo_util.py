@@ -167,6 +167,16 @@ def categorical_report(counts, probs, min_expected=5.0):
     return float(z), dof, min(1.0, pmin), int(len(pv)), (float(counts[test][worst]), float(e[test][worst])) if worst >= 0 else None
 
 
+def mismatch_cut(T: ProfileTables, mate2):
+    """Most mismatches a read without sequencing indels plausibly shows: m + 6 sqrt(m) + 2, m = what the tables expect."""
+    p_sub = T.sub[1 if mate2 else 0]
+    ident = np.array([T.bases.index(k[2]) for k in T.kmers])
+    p_mis = 1.0 - p_sub[np.arange(T.kc), :, ident]                # [kc, bins]
+    full = np.array(["X" not in k for k in T.kmers])
+    m_exp = float(p_mis[full].mean(axis=0)[(np.arange(T.L) * T.bins // T.L)].sum())
+    return int(np.ceil(m_exp + 6.0 * np.sqrt(m_exp) + 2.0))
+
+
 def sub_and_quality_counts(T: ProfileTables, fq: Fastq, src_of, rows, mate2):
     """Counts of (bin, context, called) and (bin, ref*4+called, symbol) over the records `rows` whose source bases (the
     template in read orientation, length L) `src_of(rows_chunk)` returns.  A read of nominal length can still carry an
@@ -175,12 +185,7 @@ def sub_and_quality_counts(T: ProfileTables, fq: Fastq, src_of, rows, mate2):
     m + 6 sqrt(m) + 2, with m the mismatches per read the tables expect (a Poisson tail below 1e-7 for reads without indels).
     Returns (sub counts, quality counts, reads used, mismatches)."""
     L, bins = T.L, T.bins
-    p_sub = T.sub[1 if mate2 else 0]
-    ident = np.array([T.bases.index(k[2]) for k in T.kmers])
-    p_mis = 1.0 - p_sub[np.arange(T.kc), :, ident]                # [kc, bins]
-    full = np.array(["X" not in k for k in T.kmers])
-    m_exp = float(p_mis[full].mean(axis=0)[(np.arange(L) * bins // L)].sum())
-    cut = int(np.ceil(m_exp + 6.0 * np.sqrt(m_exp) + 2.0))
+    cut = mismatch_cut(T, mate2)
     sub = np.zeros((bins, T.kc, 4), dtype=np.int64)
     qual = np.zeros((bins, 16, T.nq), dtype=np.int64)
     jbin = (np.arange(L) * bins // L).astype(np.int32)
