@@ -1230,7 +1230,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint8_t* perm = perm_all + wv * 64;
   uint8_t* permp = permp_all + wv * 64;
   uint16_t* ovf = ovf_all + wv * OVF_CAP;
-  const uint32_t TIp = TI - 1u;                          // items per plain read that run through the plain steps
+  // Items per plain read that run through the plain steps: all but the last one, whose store is partial and followed by the
+  // record separators -- unless the last item holds seven bases (L % 8 == 7, the 151-base profile): with the line break as
+  // its eighth byte it is a whole item like the others, plus the two bytes of the "+" line.  (No fewer instructions that
+  // way, but the record's last bytes leave with their neighbours instead of fifteen steps later, when the line has left
+  // L2: WRITE_SIZE 6.43 -> see profiles/r03_final.)
+  const bool tail_whole = ((uint32_t)P.L & 7u) == 7u && ((uint32_t)P.L + 7u) / 8u == TI;
+  const uint32_t TIp = tail_whole ? TI : TI - 1u;
   const uint32_t inv_TIp = TIp ? (1u << 20) / TIp + 1u : 0u;  // ceil-reciprocal (i / TIp exact while i * TIp < 2^20)
 
   // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one
@@ -1413,13 +1419,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const unsigned long long m_one = __ballot(act_l && nev_l == 1u);
     const unsigned long long m_rest = __ballot(act_l && !plain_l && nev_l == 0u);
     const uint32_t n_plain = (uint32_t)__popcll(m_plain);
+    const uint32_t n_psingle = tail_whole ? 0u : n_plain;   // plain reads' last items left to the general steps
     const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_one = (uint32_t)__popcll(m_one);
     const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // reads whose items all walk the general steps
     if (act_l) {
       if (plain_l) {
         const uint32_t pos = (uint32_t)__popcll(m_plain & lt);
         permp[pos] = (uint8_t)lane;
-        ovf[pos] = (uint16_t)(lane | (TIp << 8));   // its last item: a single item of the general stream
+        if (!tail_whole) ovf[pos] = (uint16_t)(lane | (TIp << 8));   // its last item: a single item of the general stream
       } else {
         uint32_t pos;
         if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
@@ -1436,11 +1443,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const bool small = extra == 1u || extra == 2u;
     const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
     if (small) {
-      const uint32_t o = n_plain + (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+      const uint32_t o = n_psingle + (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
       ovf[o] = (uint16_t)(lane | (TI << 8));
       if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
     }
-    const uint32_t n_ovf = n_plain + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    const uint32_t n_ovf = n_psingle + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
     unsigned long long more = __ballot(extra > 2u);
     wave_lds_sync();
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
@@ -1561,9 +1568,18 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         const bool st_ok = st.ok && !(dg & 1u);
         const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
         const uint32_t qo_ = st_ok ? st.out + (uint32_t)P.L + 3u : 0xFFFFFFFFu;
+        uint32_t fix_mask = 0xFFu;
+        if (tail_whole) {  // (wave-uniform) the read's last item: its eighth byte is the line break, then "+\n"
+          const bool last = c + 1u == TI;
+          const uint32_t sel = last ? 0x04020100u : 0x03020100u;   // v_perm: byte 3 = the first operand's byte 0 / the second's own
+          sw[1] = __builtin_amdgcn_perm(0x0Au, sw[1], sel);
+          qw[1] = __builtin_amdgcn_perm(0x0Au, qw[1], sel);
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0x0A2Bu, out_rsrc, st_ok && last ? so_ + 8u : 0xFFFFFFFFu, 0, 0);
+          fix_mask = last ? 0x7Fu : 0xFFu;
+        }
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, so_, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, qo_, 0, 0);
-        const uint32_t fix = (st.ok && !(dg & 16u)) ? (acc >> 17) & 0xFFu : 0u;
+        const uint32_t fix = (st.ok && !(dg & 16u)) ? (acc >> 17) & fix_mask : 0u;
         const unsigned long long fm = __ballot(fix != 0u);
         if (fm) {
           if (nfix + 64u > FIX_CAP) flush_fix();
@@ -1575,6 +1591,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       // (two dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
+      if (tail_whole) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0u, out_rsrc, 0xFFFFFFE0u, 0, 0);
       for (uint32_t step = 0; step < npsteps; step++) {
         const PStage nxt = fetch_plain(min(step + 1u, npsteps - 1u));
         run_plain(cur);
