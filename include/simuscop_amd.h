@@ -292,11 +292,11 @@ int sg_release_outputs(sg_ctx* ctx, sg_outputs* o);
 int sg_bgzf_eof(uint8_t out[28]);
 /* Host-only view of the code construction, for tests: from the histograms of the literal / length symbols
  * (286; [256] = end-of-block) and of the distance symbols (30), the code lengths and (bit-reversed) codes of both
- * alphabets, the length half of a match token per match length 3..64 (code + extra bits in the low 24 bits, bit count
+ * alphabets, the length half of a match token per match length 3..258 (index = length) (code + extra bits in the low 24 bits, bit count
  * in the top 8) and the member prefix (gzip header with BSIZE = 0 + dynamic block header) as LSB-first 32-bit words.
  * Returns the number of prefix bits, 0 if `cap` is too small. */
 uint32_t sg_deflate_plan(const uint64_t lit_counts[286], const uint64_t dist_counts[30], uint8_t lit_lens[286], uint32_t lit_codes[286],
-                         uint8_t dist_lens[30], uint32_t dist_codes[30], uint32_t len_tokens[65], uint32_t* prefix_words, uint32_t cap);
+                         uint8_t dist_lens[30], uint32_t dist_codes[30], uint32_t len_tokens[260], uint32_t* prefix_words, uint32_t cap);
 
 /* When enabled, HIP events bracket every kernel of sg_sample on the ctx's stream;
  * sg_kernel_times() then returns the last pass's per-kernel milliseconds (after sg_result).     */

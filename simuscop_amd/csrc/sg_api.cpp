@@ -63,7 +63,8 @@ struct DevDeflate {
   const uint32_t* prefix; uint32_t prefix_words, prefix_bits;
   const uint32_t* crc_tab; const uint32_t* crc_shift; uint32_t crc_init_full, crc_init_last;
   uint32_t* next; uint32_t* msize; const uint64_t* moff;
-  uint4* rec; uint16_t* lbits; unsigned long long* hist; uint8_t* out;
+  uint4* rec; uint32_t* lbits; unsigned long long* hist; uint8_t* out;
+  uint32_t min_run, min_copy;
 };
 void launch_gz_hist(const void* d, uint32_t n_chunks, hipStream_t s);
 void launch_gz_match(const void* d, uint32_t n_chunks, hipStream_t s);
@@ -823,7 +824,7 @@ int sg_bgzf_eof(uint8_t out[28]) {
 }
 
 uint32_t sg_deflate_plan(const uint64_t lit_counts[286], const uint64_t dist_counts[30], uint8_t lit_lens[286], uint32_t lit_codes[286],
-                         uint8_t dist_lens[30], uint32_t dist_codes[30], uint32_t len_tokens[65], uint32_t* prefix_words, uint32_t cap) {
+                         uint8_t dist_lens[30], uint32_t dist_codes[30], uint32_t len_tokens[260], uint32_t* prefix_words, uint32_t cap) {
   if (!lit_counts || !dist_counts || !lit_lens || !lit_codes || !dist_lens || !dist_codes || !len_tokens || !prefix_words) return 0;
   sg::DeflatePlan plan;
   sg::deflate_build_plan(lit_counts, dist_counts, &plan);
@@ -852,22 +853,26 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     const uint32_t n_chunks = (uint32_t)((bytes + sg::kGzChunk - 1) / sg::kGzChunk);
     // work buffer: hist[320] u64 | total u64 | counters | tables | msize[n] u32 | moff[n] u64 | block sums | lane bits | records
     const size_t head = 320 * 8 + 64;
-    const size_t tab_words = 288 + 68 + 32 + 1024 + sg::kGzLevels * 128 + 256;  // + prefix (<= 256 words)
+    const size_t tab_words = 288 + sg::kGzLenTokens + 32 + 1024 + sg::kGzLevels * 128 + 256;  // + prefix (<= 256 words)
     const size_t off_tab = head, off_msize = off_tab + tab_words * 4;
     const size_t off_moff = (off_msize + (size_t)n_chunks * 4 + 63) & ~(size_t)63;
     const size_t off_bsum = off_moff + (size_t)n_chunks * 8;
     const size_t off_lbits = (off_bsum + ((size_t)sg::scan_blocks(n_chunks) + 8) * 8 + 63) & ~(size_t)63;
-    const size_t off_rec = (off_lbits + (size_t)n_chunks * sg::kGzThreads * 2 + 63) & ~(size_t)63;
+    const size_t off_rec = (off_lbits + (size_t)n_chunks * sg::kGzThreads * 4 + 63) & ~(size_t)63;
     SG_ENSURE(ctx->gz_work, off_rec + (size_t)n_chunks * sg::kGzThreads * 32);
     uint8_t* wk = ctx->gz_work.as<uint8_t>();
     sg::DevDeflate D;
     memset(&D, 0, sizeof D);
     D.text = text; D.bytes = bytes; D.n_chunks = n_chunks;
+    D.min_run = sg::kGzMinRun;
+    D.min_copy = sg::kGzMinGramMatch;
+    if (const char* e = getenv("SG_GZ_MINCOPY")) D.min_copy = (uint32_t)std::max(8, atoi(e));   // (experiments)
+    if (const char* e = getenv("SG_GZ_MINRUN")) D.min_run = (uint32_t)std::max(3, atoi(e));   // (experiments)
     D.hist = (unsigned long long*)wk;
     D.next = (uint32_t*)(wk + 320 * 8 + 16);  // inside the zeroed head of the work buffer
     D.msize = (uint32_t*)(wk + off_msize);
     D.moff = (const uint64_t*)(wk + off_moff);
-    D.lbits = (uint16_t*)(wk + off_lbits);
+    D.lbits = (uint32_t*)(wk + off_lbits);
     D.rec = (uint4*)(wk + off_rec);
     // 1. token histogram of every 16th member -> the two Huffman codes, member prefix, CRC tables (host)
     SG_HIP(hipMemsetAsync(wk, 0, head, s));
@@ -879,18 +884,38 @@ int sg_compress(sg_ctx* ctx, uint64_t* gz_bytes_r1, uint64_t* gz_bytes_r2) {
     sg::DeflatePlan plan;
     sg::deflate_build_plan(hist, hist + 288, &plan);
     if (plan.prefix.size() > 256) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_compress: block header longer than expected");
+    if (getenv("SG_GZ_TRACE")) {   // where the sampled members' bits go: literals by character, matches by length / distance symbol
+      double lit_bits[256], tot_lit = 0, tot_len = 0, tot_dist = 0, n_match = 0, n_lit = 0, match_bytes = 0;
+      static const int lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+      static const int lext[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+      for (int c = 0; c < 256; c++) { lit_bits[c] = (double)hist[c] * plan.lit_len[c]; tot_lit += lit_bits[c]; n_lit += (double)hist[c]; }
+      for (int i = 0; i < 29; i++) { tot_len += (double)hist[257 + i] * (plan.lit_len[257 + i] + lext[i]); n_match += (double)hist[257 + i];
+                                     match_bytes += (double)hist[257 + i] * (lbase[i] + (i + 1 < 29 ? (lbase[i + 1] - lbase[i] - 1) / 2.0 : 0)); }
+      for (int i = 0; i < 30; i++) tot_dist += (double)hist[288 + i] * (plan.dist_len[i] + (i < 4 ? 0 : (i - 2) / 2));
+      const double members = (double)hist[256], all = tot_lit + tot_len + tot_dist;
+      fprintf(stderr, "[gz] per member: %.0f literals %.0f bits, %.0f matches (~%.0f bytes) %.0f length bits + %.0f distance bits; total %.0f bits = %.0f bytes\n",
+              n_lit / members, tot_lit / members, n_match / members, match_bytes / members, tot_len / members, tot_dist / members, all / members, all / members / 8);
+      fprintf(stderr, "[gz] literal bits per member by character:");
+      for (int c = 0; c < 256; c++)
+        if (lit_bits[c] / members >= 20) fprintf(stderr, " '%c'x%.0f(%d b)=%.0f", c >= 32 && c < 127 ? c : '?', hist[c] / members, plan.lit_len[c], lit_bits[c] / members);
+      fprintf(stderr, "\n[gz] matches per member by length symbol:");
+      for (int i = 0; i < 29; i++) if (hist[257 + i] / members >= 1) fprintf(stderr, " %d+:%0.f(%d b)", lbase[i], hist[257 + i] / members, plan.lit_len[257 + i] + lext[i]);
+      fprintf(stderr, "\n[gz] distance symbols:");
+      for (int i = 0; i < 30; i++) if (hist[288 + i] / members >= 1) fprintf(stderr, " %d:%.0f(%d b)", i, hist[288 + i] / members, plan.dist_len[i] + (i < 4 ? 0 : (i - 2) / 2));
+      fprintf(stderr, "\n");
+    }
     std::vector<uint32_t> tab(tab_words, 0);
     for (int i = 0; i < sg::kGzLitSyms; i++) tab[i] = plan.lit_code[i] | ((uint32_t)plan.lit_len[i] << 16);
     memcpy(&tab[288], plan.len_token, sizeof plan.len_token);
-    for (int i = 0; i < sg::kGzDistSyms; i++) tab[288 + 68 + i] = plan.dist_code[i] | ((uint32_t)plan.dist_len[i] << 16);
-    const size_t t_crc = 288 + 68 + 32;
+    for (int i = 0; i < sg::kGzDistSyms; i++) tab[288 + sg::kGzLenTokens + i] = plan.dist_code[i] | ((uint32_t)plan.dist_len[i] << 16);
+    const size_t t_crc = 288 + sg::kGzLenTokens + 32;
     memcpy(&tab[t_crc], plan.crc_table, sizeof plan.crc_table);
     memcpy(&tab[t_crc + 1024], plan.crc_shift, sizeof plan.crc_shift);
     memcpy(&tab[t_crc + 1024 + sg::kGzLevels * 128], plan.prefix.data(), plan.prefix.size() * 4);
     SG_HIP(hipMemcpyAsync(wk + off_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     D.code = (const uint32_t*)(wk + off_tab);
     D.len_tok = D.code + 288;
-    D.dist_code = D.len_tok + 68;
+    D.dist_code = D.len_tok + sg::kGzLenTokens;
     D.crc_tab = D.dist_code + 32;
     D.crc_shift = D.crc_tab + 1024;
     D.prefix = D.crc_shift + sg::kGzLevels * 128;

@@ -124,9 +124,9 @@ void deflate_build_plan(const uint64_t lit_counts[kGzLitSyms], const uint64_t di
   for (int i = 0; i < kGzLitSyms; i++) freq[i] = lit_counts[i] + 1;  // [256]: one end-of-block per sampled member
   limited_lengths(freq, kGzLitSyms, 15, plan->lit_len);
   canonical_codes(plan->lit_len, kGzLitSyms, plan->lit_code);
-  for (uint32_t L = 0; L <= kGzMaxMatch; L++) {
+  for (uint32_t L = 0; L < kGzLenTokens; L++) {
     plan->len_token[L] = 0;
-    if (L < 3) continue;
+    if (L < 3 || L > 258) continue;
     uint32_t eb, ev;
     const int sym = 257 + deflate_length_symbol(L, &eb, &ev);
     const uint32_t nb = plan->lit_len[sym];

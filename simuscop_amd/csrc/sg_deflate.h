@@ -26,9 +26,11 @@ constexpr int kGzLitSyms = 286;          // literal / length alphabet: 256 liter
 constexpr int kGzDistSyms = 30;          // distance alphabet
 constexpr uint32_t kGzGram = 8;          // bytes hashed per position
 constexpr uint32_t kGzHashBits = 13;     // first-occurrence table: 8192 entries in LDS
-constexpr uint32_t kGzMinGramMatch = 8;  // shortest match taken from the table (and only where the run is shorter than that)
+constexpr uint32_t kGzMinGramMatch = 12; // shortest copy taken from the table where literals are cheap (quality lines); base lines and names: 8
 constexpr uint32_t kGzMinRun = 5;        // shortest match taken at distance 1
-constexpr uint32_t kGzMaxMatch = 64;     // a match never leaves its lane's 64 bytes (RFC limit: 258)
+constexpr uint32_t kGzMaxMatch = 64;     // a lane's match never leaves its 64 bytes ...
+constexpr uint32_t kGzMaxToken = 256;    // ... but matches of up to four neighbouring lanes that continue one copy leave as one token (RFC limit: 258)
+constexpr uint32_t kGzLenTokens = 260;   // entries of the length-token table (index = match length)
 constexpr uint32_t kGzLaneMatches = 6;   // matches per lane; what follows them in the lane is literals
 constexpr uint32_t kGzSamples = 512;     // members sampled for the token histogram (16 MB of text), spread evenly
 
@@ -42,9 +44,9 @@ struct DeflatePlan {
   uint32_t lit_code[kGzLitSyms];   // canonical codes, bit-reversed for LSB-first packing
   uint8_t dist_len[kGzDistSyms];   // the distance code, likewise
   uint32_t dist_code[kGzDistSyms];
-  // the length half of a match token of length L (3..64): length code and its extra bits, LSB-first in the low 24
+  // the length half of a match token of length L (3..256): length code and its extra bits, LSB-first in the low 24
   // bits, the bit count in the top 8
-  uint32_t len_token[kGzMaxMatch + 1];
+  uint32_t len_token[kGzLenTokens];
   std::vector<uint32_t> prefix;    // the first prefix_bits of every member (header, BSIZE = 0, block header), LSB-first words
   uint32_t prefix_bits = 0;
   // CRC-32 machinery (reflected polynomial 0xEDB88320)

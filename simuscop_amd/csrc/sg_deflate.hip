@@ -46,9 +46,11 @@ struct DevDeflate {
   uint32_t* msize;            // [n_chunks] member bytes
   const uint64_t* moff;       // [n_chunks] member offsets
   uint4* rec;                 // [n_chunks * 512 * 2] token records
-  uint16_t* lbits;            // [n_chunks * 512] bits of a lane's tokens
+  uint32_t* lbits;            // [n_chunks * 512] bits of a lane's tokens | bytes its last match takes over from the next lanes << 10
   unsigned long long* hist;   // [320] literal/length counts, then distance counts at 288
   uint8_t* out;
+  uint32_t min_run;           // shortest match taken at distance 1 (kGzMinRun)
+  uint32_t min_copy;          // shortest copy taken from the table (kGzMinGramMatch)
 };
 
 constexpr uint32_t kGzTab = 1u << kGzHashBits;
@@ -135,7 +137,8 @@ __device__ __forceinline__ uint32_t gz_dist_symbol(uint32_t d1, uint32_t* eb) { 
   *eb = lg - 1u;
   return 2u * lg + ((d1 >> (lg - 1u)) & 1u);
 }
-__device__ __forceinline__ uint32_t gz_len_symbol(uint32_t len) {  // 3..64 -> 257..
+__device__ __forceinline__ uint32_t gz_len_symbol(uint32_t len) {  // 3..258 -> 257..285
+  if (len == 258u) return 285u;
   const uint32_t l3 = len - 3u;
   if (l3 < 8u) return 257u + l3;
   const uint32_t lg = 31u - (uint32_t)__builtin_clz(l3);
@@ -266,6 +269,24 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
       }
       const uint32_t s0 = k - back;
       len += back;
+      // A short copy from far away (five or six bits of length code, fourteen to sixteen of distance) costs more than
+      // its bytes as literals where literals are cheap: quality lines, whose few symbols get two- to four-bit codes.
+      // Base lines (four-bit literals) and names (seven-bit digits) gain from eight bytes on.  Told apart by the gram
+      // itself: six of its eight bytes A/C/G/T, or a '#' of a read name in it.
+      if (len < D.min_copy) {
+        auto eq = [](uint64_t x, uint64_t c) {   // 0x80 in every byte of x equal to c
+          const uint64_t y = x ^ (c * 0x0101010101010101ull);
+          return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
+        };
+        const uint32_t acgt = (uint32_t)__popcll(eq(own, 'A') | eq(own, 'C') | eq(own, 'G') | eq(own, 'T'));
+        if (acgt < 6u && !eq(own, '#')) {
+          // the probes inside the span just seen would find the same short copy again: on to the first gram that leaves it
+          const uint32_t past = s0 + len - 7u;
+          const uint32_t below = 2u * (past >> 2) + ((past & 3u) < 2u ? (past & 3u) : 2u);
+          todo &= below >= 32u ? 0u : ~((1u << below) - 1u);
+          continue;
+        }
+      }
       if (nm < 4u) gq |= (uint64_t)(q - cq - 1u) << (15u * nm);
       else gq2 |= (q - cq - 1u) << (15u * (nm - 4u));
       nm++;
@@ -290,7 +311,7 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
       uint32_t len = ones + 3u;
       len = len < room ? len : room;
       const uint64_t stretch = (ones >= 64u ? ~0ull : ((1ull << ones) - 1ull)) << s0;
-      if (len >= kGzMinRun) {
+      if (len >= D.min_run) {
         starts |= 1ull << s0;
         cover |= (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << s0;
         nm++;
@@ -324,6 +345,57 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
   }
 }
 
+// One copy that runs through several lanes leaves as ONE token.  gz_tokens cuts every match at its lane's end (that is
+// what makes the lanes independent); a read's 151 bases, copied from an earlier read of the same window, so became three
+// or four matches of the same distance -- each with its own length and distance code, ~20 bits.  Inside every aligned
+// group of four lanes (256 bytes, the most a group's copy can reach; the format allows 258): a lane's FIRST match, if it
+// starts at the lane's first byte with the distance of the previous lane's LAST match, which ends at that lane's last
+// byte, is ABSORBED -- it emits nothing, the earlier match grows by its length, and through a lane that one match covers
+// whole the copy runs on.  Order-independent like the rest: every lane decides from its neighbours' descriptors.
+//   returns: bit 0 this lane's first match is absorbed; bits 8.. bytes this lane's last match takes over from later lanes
+//   scratch: 2 x kGzThreads words (the hash table's space: nobody reads the table any more)
+__device__ __forceinline__ uint32_t gz_merge(const GzLane& L, uint32_t* scratch) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nm = (uint32_t)__popcll(L.starts);
+  uint32_t last = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < kGzLaneMatches; j++) last = (j + 1u == nm) ? L.mw[j] : last;
+  // descriptor: length | distance - 1 << 8 | 1 << 31, 0 = none
+  const bool f_ok = L.first == 0u && (L.starts & 1ull) != 0ull;
+  const bool e_ok = nm != 0u && (L.cover >> 63) != 0ull;
+  const uint32_t fd = f_ok ? (((L.mw[0] & 63u) + 3u) | (((L.mw[0] >> 6) & 0x7FFFu) << 8) | 0x80000000u) : 0u;
+  const uint32_t ed = e_ok ? (((last & 63u) + 3u) | (((last >> 6) & 0x7FFFu) << 8) | 0x80000000u) : 0u;
+  __syncthreads();   // every lane is done with the table
+  scratch[lane] = fd;
+  scratch[kGzThreads + lane] = ed;
+  __syncthreads();
+  const uint32_t g = lane & 3u, base = lane - g;
+  uint32_t F[4], E[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; j++) { F[j] = scratch[base + j]; E[j] = scratch[kGzThreads + base + j]; }
+  bool ab[4], whole[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; j++) {
+    ab[j] = j > 0u && (F[j] >> 31) && (E[j > 0u ? j - 1u : 0u] >> 31) && ((F[j] ^ E[j > 0u ? j - 1u : 0u]) & 0x7FFFFF00u) == 0u;
+    whole[j] = (F[j] >> 31) && (F[j] & 0xFFu) == 64u;
+  }
+  uint32_t mine = 0, extra = 0;
+  bool run = true;
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; j++) {
+    if (j == g) mine = ab[j] ? 1u : 0u;
+    // lanes after this one: absorbed one after the other while the copy goes on
+    if (j > g) {
+      run = run && ab[j];
+      if (run) extra += F[j] & 0xFFu;
+      run = run && whole[j];
+    }
+  }
+  // this lane's last match only grows if it is a match of its own: not a whole-lane match that was itself absorbed
+  if (!(E[g] >> 31) || (mine && whole[g])) extra = 0;
+  return mine | (extra << 8);
+}
+
 __global__ __launch_bounds__(kGzThreads, 4) void gz_hist_kernel(DevDeflate D) {
   extern __shared__ uint32_t gz_smem[];
   uint32_t* tab = gz_smem;                                  // [kGzTab]
@@ -339,12 +411,14 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_hist_kernel(DevDeflate D) {
     GzLane L;
     if (n == kGzChunk) gz_tokens<true>(D, c, n, txt, tab, L);
     else gz_tokens<false>(D, c, n, txt, tab, L);
+    const uint32_t mg = gz_merge(L, tab);
+    const uint32_t nm_h = (uint32_t)__popcll(L.starts);
 #pragma unroll
     for (uint32_t j = 0; j < kGzLaneMatches; j++) {
       const uint32_t v = L.mw[j];
-      if (v >> 31) {
+      if ((v >> 31) && !(j == 0u && (mg & 1u))) {
         uint32_t eb;
-        atomicAdd(&h[gz_len_symbol((v & 63u) + 3u)], 1u);
+        atomicAdd(&h[gz_len_symbol((v & 63u) + 3u + (j + 1u == nm_h ? mg >> 8 : 0u))], 1u);
         atomicAdd(&h[288u + gz_dist_symbol((v >> 6) & 0x7FFFu, &eb)], 1u);
       }
     }
@@ -365,11 +439,11 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
   uint8_t* txt = (uint8_t*)(tab + kGzTab + 4);              // [kGzChunk + pad]
   uint32_t* code = (uint32_t*)(txt + kGzChunk + kGzTxtPad); // [288] literal/length, [68] length tokens, [32] distance
   uint32_t* len_tok = code + 288;
-  uint32_t* dist_code = len_tok + 68;
+  uint32_t* dist_code = len_tok + kGzLenTokens;
   uint32_t* wave_tot = dist_code + 32;                      // [8]
   __shared__ uint32_t next_c;
   for (uint32_t i = threadIdx.x; i < 288u; i += kGzThreads) code[i] = D.code[i];
-  for (uint32_t i = threadIdx.x; i < 68u; i += kGzThreads) len_tok[i] = D.len_tok[i];
+  for (uint32_t i = threadIdx.x; i < kGzLenTokens; i += kGzThreads) len_tok[i] = D.len_tok[i];
   for (uint32_t i = threadIdx.x; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
   __syncthreads();
   for (uint32_t c = blockIdx.x; c < D.n_chunks;) {
@@ -378,15 +452,20 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
     GzLane L;
     if (n == kGzChunk) gz_tokens<true>(D, c, n, txt, tab, L);
     else gz_tokens<false>(D, c, n, txt, tab, L);
+    // copies that run on through the next lanes become one token (gz_merge)
+    const uint32_t mg = gz_merge(L, tab);
+    const uint32_t nm = (uint32_t)__popcll(L.starts);
+    if (mg & 1u) L.mw[0] |= 0x7FFFu << 6;   // an absorbed match: no distance this large exists inside a member
     // bits of the matches, in order, one byte each
     uint64_t jumps = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kGzLaneMatches; j++) {
       const uint32_t v = L.mw[j];
-      if (v >> 31) {
+      if ((v >> 31) && !(j == 0u && (mg & 1u))) {
         uint32_t eb;
         const uint32_t ds = gz_dist_symbol((v >> 6) & 0x7FFFu, &eb);
-        jumps |= (uint64_t)((len_tok[(v & 63u) + 3u] >> 24) + (dist_code[ds] >> 16) + eb) << (8u * j);
+        const uint32_t len = (v & 63u) + 3u + (j + 1u == nm ? mg >> 8 : 0u);
+        jumps |= (uint64_t)((len_tok[len] >> 24) + (dist_code[ds] >> 16) + eb) << (8u * j);
       }
     }
     // one pass over the lane's bytes: code lengths of the literals; the bit offset at which each match starts (ten bits
@@ -402,7 +481,6 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
       const uint32_t cl = code[(L.w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu] >> 16;
       bits += (k >= L.first && !((L.cover >> k) & 1ull)) ? cl : 0u;
     }
-    const uint32_t nm = (uint32_t)__popcll(L.starts);
     offs = nm ? offs >> (10u * (kGzLaneMatches - nm)) : 0ull;
     uint32_t mw[kGzLaneMatches];
 #pragma unroll
@@ -411,7 +489,7 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
     uint4* rec = D.rec + ((size_t)c * kGzThreads + threadIdx.x) * 2;
     rec[0] = make_uint4((uint32_t)L.starts, (uint32_t)(L.starts >> 32), mw[0], mw[1]);
     rec[1] = make_uint4(mw[2], mw[3], mw[4], mw[5]);
-    D.lbits[(size_t)c * kGzThreads + threadIdx.x] = (uint16_t)bits;
+    D.lbits[(size_t)c * kGzThreads + threadIdx.x] = bits | ((mg >> 8) << 10);
     uint32_t total;
     gz_block_scan(bits, wave_tot, &total);
     if (threadIdx.x == 0) {
@@ -428,15 +506,15 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
   extern __shared__ uint32_t gz_smem[];
   uint32_t* stage = gz_smem;                       // [stage_words]
   uint32_t* code = stage + stage_words;            // [288]
-  uint32_t* len_tok = code + 288;                  // [68]
-  uint32_t* dist_code = len_tok + 68;              // [32]
+  uint32_t* len_tok = code + 288;                  // [kGzLenTokens]
+  uint32_t* dist_code = len_tok + kGzLenTokens;    // [32]
   uint32_t* crc_tab = dist_code + 32;              // [4][256]
   uint32_t* crc_shift = crc_tab + 1024;            // [kGzLevels][8][16]
   uint32_t* crcs = crc_shift + kGzLevels * 128;    // [kGzThreads]
   uint32_t* wave_tot = crcs + kGzThreads;          // [8]
   const uint32_t lane = threadIdx.x;
   for (uint32_t i = lane; i < 288u; i += kGzThreads) code[i] = D.code[i];
-  for (uint32_t i = lane; i < 68u; i += kGzThreads) len_tok[i] = D.len_tok[i];
+  for (uint32_t i = lane; i < kGzLenTokens; i += kGzThreads) len_tok[i] = D.len_tok[i];
   for (uint32_t i = lane; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
   for (uint32_t i = lane; i < 1024; i += kGzThreads) crc_tab[i] = D.crc_tab[i];
   for (uint32_t i = lane; i < kGzLevels * 128; i += kGzThreads) crc_shift[i] = D.crc_shift[i];
@@ -453,7 +531,8 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
     const uint32_t first = gz_load_lane(D, c, lane, n, w);
     const uint4* rec = D.rec + ((size_t)c * kGzThreads + lane) * 2;
     const uint4 ra = rec[0], rb = rec[1];
-    const uint32_t bits = D.lbits[(size_t)c * kGzThreads + lane];
+    const uint32_t lb = D.lbits[(size_t)c * kGzThreads + lane];
+    const uint32_t bits = lb & 0x3FFu, extra = lb >> 10;   // extra: bytes of the next lanes the lane's last match copies too
     uint32_t total;
     const uint32_t excl = gz_block_scan(bits, wave_tot, &total);  // its barrier also orders the zeroing above
     const uint32_t base = D.prefix_bits + excl;
@@ -473,9 +552,10 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
           const uint32_t s = (uint32_t)__builtin_ctzll(st);
           st &= st - 1ull;
           cover |= (len == 64u ? ~0ull : ((1ull << len) - 1ull)) << s;
+          if (d1 == 0x7FFFu) continue;   // absorbed by the previous lane's last match: covered, no token
           uint32_t eb;
           const uint32_t ds = gz_dist_symbol(d1, &eb);
-          const uint32_t lt = len_tok[len], dc = dist_code[ds];
+          const uint32_t lt = len_tok[len + (st == 0ull ? extra : 0u)], dc = dist_code[ds];
           const uint32_t n1 = lt >> 24, n2 = dc >> 16;
           const uint64_t tok = (uint64_t)(lt & 0xFFFFFFu) | ((uint64_t)(dc & 0xFFFFu) << n1) | ((uint64_t)(d1 & ((1u << eb) - 1u)) << (n1 + n2));
           const uint32_t nb = n1 + n2 + eb;  // <= 48
@@ -560,7 +640,7 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
-static size_t gz_token_lds() { return ((size_t)kGzTab + 4 + 288 + 68 + 32 + 8 + 64) * 4 + kGzChunk + kGzTxtPad; }
+static size_t gz_token_lds() { return ((size_t)kGzTab + 4 + 288 + kGzLenTokens + 32 + 8 + 64) * 4 + kGzChunk + kGzTxtPad; }
 void launch_gz_hist(const void* d, uint32_t n_chunks, hipStream_t s) {
   if (!n_chunks) return;
   const size_t lds = gz_token_lds();
@@ -582,7 +662,7 @@ void launch_gz_match(const void* d, uint32_t n_chunks, hipStream_t s) {
 void launch_gz_encode(const void* d, uint32_t n_chunks, uint32_t prefix_bits, hipStream_t s) {
   if (!n_chunks) return;
   const uint32_t sw = gz_stage_words(prefix_bits);
-  const size_t lds = ((size_t)sw + 288 + 68 + 32 + 1024 + kGzLevels * 128 + kGzThreads + 8) * 4;
+  const size_t lds = ((size_t)sw + 288 + kGzLenTokens + 32 + 1024 + kGzLevels * 128 + kGzThreads + 8) * 4;
   (void)hipFuncSetAttribute((const void*)gz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const uint32_t grid = n_chunks < 512u ? n_chunks : 512u;  // two workgroups per CU fit in LDS
   hipLaunchKernelGGL(gz_encode_kernel, dim3(grid), dim3(kGzThreads), lds, s, *(const DevDeflate*)d, sw);

@@ -81,7 +81,7 @@ def _plan(lit, dist):
     c1 = (C.c_uint64 * 286)(*[int(x) for x in lit])
     c2 = (C.c_uint64 * 30)(*[int(x) for x in dist])
     l1, l2 = C.create_string_buffer(286), C.create_string_buffer(30)
-    k1, k2, lt = (C.c_uint32 * 286)(), (C.c_uint32 * 30)(), (C.c_uint32 * 65)()
+    k1, k2, lt = (C.c_uint32 * 286)(), (C.c_uint32 * 30)(), (C.c_uint32 * 260)()
     prefix = (C.c_uint32 * 256)()
     bits = eng.sg_deflate_plan(c1, c2, l1, k1, l2, k2, lt, prefix, 256)
     assert bits > 144
@@ -179,7 +179,7 @@ def test_a_plan_from_one_text_encodes_another():
 
 def test_length_tokens_follow_rfc1951():
     P = _plan(np.ones(286, np.int64), np.ones(30, np.int64))
-    for length in range(3, 65):
+    for length in range(3, 259):
         s = _lsym(length)
         lt = P["len_token"][length]
         nb = int(P["lit_len"][257 + s])
