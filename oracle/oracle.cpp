@@ -704,8 +704,8 @@ struct ReadCtx {
     const uint32_t call = (uint32_t)(i >> 2), l = (uint32_t)i & 3u;
     if (call != cachedCall || mate != cachedMate) {
       cachedMate = mate;
-      heads = philox4x32_10(slot, call, 0, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
-      tails = philox4x32_10(slot, call, 1, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
+      heads = philox4x32_r(kBaseRounds, slot, call, 0, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
+      tails = philox4x32_r(kBaseRounds, slot, call, 1, KIND_BASE | (ctx24() << 8), rng->k0, rng->k1);
       cachedCall = call;
     }
     const uint32_t wh = heads.v[l], wt = tails.v[l];

@@ -14,6 +14,11 @@ constexpr size_t kTotalsSegBase = 128 + 2 * 2 * 8 * 128;
 constexpr size_t kTotalsBytes = kTotalsSegBase + 2 * 16 * 8 + 64;
 
 // RNG stream kinds (DESIGN.md "RNG addressing"); c3 = kind | (ctx24 << 8)
+// Rounds of the per-base draws (KIND_BASE: two calls per eight sampled bases, 97 % of all calls).  Seven is the smallest
+// round count of Philox4x32 its authors report as passing BigCrush (Salmon et al., SC'11; Random123's documented
+// minimum); every other stream keeps their default of ten.  Specified in oracle/philox.h alike.
+constexpr int kBaseRounds = 7;
+
 enum : uint32_t { KIND_HAP = 1, KIND_GC = 2, KIND_PLAN = 3, KIND_INDEL = 4, KIND_AUX = 5, KIND_BASE = 6 };
 
 // One planned fragment (16 B).  Written by plan_kernel, read by the indel and emit kernels.

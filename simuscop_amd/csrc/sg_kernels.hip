@@ -27,11 +27,12 @@ namespace sg {
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11), one call = four 32-bit draws
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+template <int ROUNDS>
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -43,6 +44,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  philox4x32<10>(c0, c1, c2, c3, k0, k1, out);
+}
+// the per-base draws (KIND_BASE): kBaseRounds rounds (sg_device.h)
+__device__ __forceinline__ void philox_base(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  philox4x32<kBaseRounds>(c0, c1, c2, c3, k0, k1, out);
 }
 
 __device__ __forceinline__ uint32_t dev_ctx(uint32_t kind, uint32_t mate, uint32_t batch) {
@@ -744,8 +752,8 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     if (B.diag & 8u) {
       for (int z = 0; z < 4; z++) { xh[4 * g + z] = (slot * 2654435761u) ^ (c * 40503u + (4 * g + z) * 0x9E3779B9u); xt[4 * g + z] = ~xh[4 * g + z]; }
     } else {
-      philox4x32_10(slot + B.slot_offset, 2u * c + (uint32_t)g, 0, c3b, B.k0, B.k1, xh + 4 * g);
-      philox4x32_10(slot + B.slot_offset, 2u * c + (uint32_t)g, 1, c3b, B.k0, B.k1, xt + 4 * g);
+      philox_base(slot + B.slot_offset, 2u * c + (uint32_t)g, 0, c3b, B.k0, B.k1, xh + 4 * g);
+      philox_base(slot + B.slot_offset, 2u * c + (uint32_t)g, 1, c3b, B.k0, B.k1, xt + 4 * g);
     }
   }
   const uint32_t lgW = P.lgW;
@@ -961,7 +969,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // "tails" word of output position i0 + h (KIND_BASE call (2c + h/4, 1)); rare, kept out of line
 __device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h, uint32_t c3b, uint32_t k0, uint32_t k1) {
   uint32_t y[4];
-  philox4x32_10(slot, 2u * c + (h >> 2), 1u, c3b, k0, k1, y);
+  philox_base(slot, 2u * c + (h >> 2), 1u, c3b, k0, k1, y);
   const uint32_t l = h & 3u;
   return l == 0u ? y[0] : l == 1u ? y[1] : l == 2u ? y[2] : y[3];
 }
@@ -1097,8 +1105,8 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 #pragma unroll
     for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
   } else {
-    philox4x32_10(slot + B.slot_offset, 2u * c, 0, c3b, B.k0, B.k1, x);
-    philox4x32_10(slot + B.slot_offset, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+    philox_base(slot + B.slot_offset, 2u * c, 0, c3b, B.k0, B.k1, x);
+    philox_base(slot + B.slot_offset, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
   }
 
   // ---- table offsets of the eight positions: bin * block bytes (+ the short-context region of a read's first two
@@ -1348,7 +1356,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           const uint32_t i = 8u * c + h;
           const uint32_t bin = __umulhi(__umul24(i, bins), inv);
           uint32_t xw[4];
-          philox4x32_10(slot, 2u * c + (h >> 2), 0, c3b, B.k0, B.k1, xw);
+          philox_base(slot, 2u * c + (h >> 2), 0, c3b, B.k0, B.k1, xw);
           const uint32_t l = h & 3u;
           const uint32_t wh = l == 0u ? xw[0] : l == 1u ? xw[1] : l == 2u ? xw[2] : xw[3];
           const uint32_t region = c == 0u ? (h == 0u ? 128u : h == 1u ? 64u : 0u) : 0u;
@@ -1557,8 +1565,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
 #pragma unroll
           for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
         } else {
-          philox4x32_10(slot, 2u * c, 0, c3b, B.k0, B.k1, x);
-          philox4x32_10(slot, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+          philox_base(slot, 2u * c, 0, c3b, B.k0, B.k1, x);
+          philox_base(slot, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
         }
         const uint4* lrow = (const uint4*)(lut + c * LUT_ROW);
         const uint4 r0 = lrow[0], r1 = lrow[1], r2 = lrow[2];
