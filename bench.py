@@ -138,7 +138,7 @@ def pmc_evidence():
         return None
     path, v = best
     meta = json.load(open(path)).get("_meta", {})
-    out = {"source": os.path.relpath(path, ROOT), "kernel_ms_profiled": meta.get("emit_fast_kernel_avg_ms"),
+    out = {"source": os.path.relpath(path, ROOT), "kernel_ms_profiled": meta.get("emit_fast_kernel_avg_ms"), "digest": meta.get("engine_source_digest"),
            "traffic": (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0}
     if "SQ_INSTS_VALU" in v:
         out["valu"] = v["SQ_INSTS_VALU"]["mean_per_dispatch"]
@@ -346,15 +346,15 @@ def main():
         achieved = pairs_per_step * bytes_per_pair * main_share / (emit_ms * 1e-3) / 1e9
         pmc = pmc_evidence() if default_workload else None
         pmc_stale = None
-        if pmc and pmc.get("kernel_ms_profiled"):
-            # counters of another build say nothing about this one: the profiled launch must have lasted what the live one does
-            # (profiled passes run 3-5 % slower than unprofiled ones; 10 % is a different kernel)
-            if abs(pmc["kernel_ms_profiled"] - emit_ms) > 0.10 * emit_ms:
-                pmc_stale = {"source": pmc["source"], "kernel_ms_profiled": pmc["kernel_ms_profiled"], "kernel_ms_live": emit_ms}
+        if pmc:
+            # Counters of another build say nothing about this one: they are quoted only when they were taken on exactly the
+            # engine sources this run uses (tools/profile_round.sh stores their digest with the counters).  The profiled
+            # launch's time is reported next to the live one; boxes differ by up to ~10 % on this kernel.
+            from simuscop_amd.build import engine_source_digest
+            now = engine_source_digest()
+            if pmc.get("digest") != now:
+                pmc_stale = {"source": pmc["source"], "counters_taken_on_sources": pmc.get("digest"), "this_run": now}
                 pmc = None
-        elif pmc:
-            pmc_stale = {"source": pmc["source"], "reason": "no kernel time recorded with the counters (profiles older than round 3)"}
-            pmc = None
         compute_side = None
         if pmc and "valu" in pmc:
             # VALU issue occupancy of the LIVE launch: wave-instructions of the committed counter pass (the count does not
@@ -390,6 +390,7 @@ def main():
                          "traffic_unit": "bytes per launch",
                          "traffic_source": pmc["source"] if pmc else None,
                          "traffic_refused_as_stale": pmc_stale,
+                         "kernel_ms_of_the_profiled_run": pmc.get("kernel_ms_profiled") if pmc else None,
                          "algorithmic_bytes_per_launch": pairs_per_step * bytes_per_pair * main_share,
                          "kernel": "emit_fast_kernel", "kernel_ms": emit_ms,
                          "items_left_to_emit_slow_kernel": 1.0 - main_share, "emit_slow_kernel_ms": slow_ms,

@@ -80,6 +80,19 @@ def build_host(force=False, verbose=False):
     return so, exe
 
 
+def engine_source_digest():
+    """sha256 over the engine's sources (csrc/*.hip, *.cpp, *.h; the C ABI header): what counters and traces were taken
+    on.  tools/profile_round.sh stores it with the counters, bench.py quotes counters only of the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(INCLUDE, "simuscop_amd.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_all(force=False, verbose=False):
     eng = build_engine(force, verbose)
     host, exe = build_host(force, verbose)

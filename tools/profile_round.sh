@@ -25,7 +25,9 @@ for row in csv.DictReader(open(out + "/kernel_stats.csv", newline="")):
     if "emit_fast_kernel" in row["Name"]:
         ms = float(row["AverageNs"]) / 1e6
 d = json.load(open(out + "/pmc_summary.json"))
-d["_meta"] = {"emit_fast_kernel_avg_ms": ms, "from": "kernel_stats.csv of the same profile_round.sh run"}
+sys.path.insert(0, ".")
+from simuscop_amd.build import engine_source_digest
+d["_meta"] = {"emit_fast_kernel_avg_ms": ms, "from": "kernel_stats.csv of the same profile_round.sh run", "engine_source_digest": engine_source_digest()}
 json.dump(d, open(out + "/pmc_summary.json", "w"), indent=1)
 PY
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
