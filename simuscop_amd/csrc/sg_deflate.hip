@@ -272,14 +272,15 @@ __device__ __forceinline__ void gz_tokens(const DevDeflate& D, uint32_t c, uint3
       // A short copy from far away (five or six bits of length code, fourteen to sixteen of distance) costs more than
       // its bytes as literals where literals are cheap: quality lines, whose few symbols get two- to four-bit codes.
       // Base lines (four-bit literals) and names (seven-bit digits) gain from eight bytes on.  Told apart by the gram
-      // itself: six of its eight bytes A/C/G/T, or a '#' of a read name in it.
+      // itself: A/C/G/T bytes, or a '#' of a read name in it.
       if (len < D.min_copy) {
-        auto eq = [](uint64_t x, uint64_t c) {   // 0x80 in every byte of x equal to c
-          const uint64_t y = x ^ (c * 0x0101010101010101ull);
-          return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
-        };
-        const uint32_t acgt = (uint32_t)__popcll(eq(own, 'A') | eq(own, 'C') | eq(own, 'G') | eq(own, 'T'));
-        if (acgt < 6u && !eq(own, '#')) {
+        // (three bytes of the gram stand for it: its first, fourth and last -- A/C/G/T by one shift of a bit set each)
+        auto acgt = [](uint32_t c) { const uint32_t d = c - 65u; return d < 20u ? (0x80045u >> d) & 1u : 0u; };
+        const uint32_t lo32 = (uint32_t)own, hi32 = (uint32_t)(own >> 32);
+        const uint32_t votes = acgt(lo32 & 0xFFu) + acgt(lo32 >> 24) + acgt(hi32 >> 24);
+        const uint32_t x = lo32 ^ 0x23232323u, y = hi32 ^ 0x23232323u;   // a '#' of a read name in the gram?
+        const bool hash = ((((x - 0x01010101u) & ~x) | ((y - 0x01010101u) & ~y)) & 0x80808080u) != 0u;
+        if (votes < 3u && !hash) {
           // the probes inside the span just seen would find the same short copy again: on to the first gram that leaves it
           const uint32_t past = s0 + len - 7u;
           const uint32_t below = 2u * (past >> 2) + ((past & 3u) < 2u ? (past & 3u) : 2u);
