@@ -1874,6 +1874,11 @@ extern "C" int orc_predict_philox(const orc_profile* h, const char* ref, int n, 
   memcpy(out_quals, q.data(), np);
   return np;
 }
+extern "C" void orc_philox4x32_r(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  orc::Philox4 o = orc::philox4x32_r(rounds, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  for (int i = 0; i < 4; i++) out[i] = o.v[i];
+}
+extern "C" int orc_base_rounds(void) { return orc::kBaseRounds; }
 extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   orc::Philox4 o = orc::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
   for (int i = 0; i < 4; i++) out[i] = o.v[i];

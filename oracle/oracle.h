@@ -72,8 +72,10 @@ typedef struct orc_train_counts {
 int orc_train_count(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* bases, int kmer, int bins,
                     uint32_t n_isize, orc_train_counts* out);
 
-// Philox known-answer helper
+// Philox known-answer helpers (orc_base_rounds: the round count of the per-base draws, philox.h kBaseRounds)
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox4x32_r(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int orc_base_rounds(void);
 
 #ifdef __cplusplus
 }
