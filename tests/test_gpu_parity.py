@@ -266,3 +266,24 @@ def test_a_stale_fasta_index_is_not_trusted(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     for f in _files(one):
         assert sorted(_records(open(os.path.join(d, f), "rb").read())) == sorted(_records(open(os.path.join(one, f), "rb").read())), f
+
+
+def test_default_bench_line_on_two_ranks():
+    """The command the driver's scaling run uses -- `bench.py --gpus N`, no workload flag -- on two ranks sharing the device
+    (gloo rehearsal of the RCCL collectives): one line with the weak C2 figure of both ranks AND the strong-scaling leg of one
+    genome over both (`strong_c3`), whose ranks' pairs add up to the genome's."""
+    import json
+    import sys
+    from simuscop_amd import synth
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--contig-len", "8000000", "--strong-scale", "0.02", "--no-md5"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, BENCH_SAME_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    leg = line["strong_c3"]
+    assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and len(leg["per_rank"]) == 2
+    want = sum(length for _, length in synth.grch38_contigs(0.02)) * 30 / 151 / 2
+    assert abs(leg["pairs_per_run"] - want) < 0.02 * want
+    assert abs(sum(v["pairs_per_step"] for v in leg["per_rank"]) - leg["pairs_per_run"]) < 1e-6 * want
+    assert all(v["pairs_per_step"] > 0.4 * leg["pairs_per_run"] for v in leg["per_rank"])
