@@ -208,174 +208,223 @@ __device__ __forceinline__ uint64_t rec_offset(const DevBatch& B, uint32_t m, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// indel pass: one lane per read
+// indel pass: one lane per fragment
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void indel_kernel(DevProfile P, DevBatch B) {
+  // lane = fragment, both of its reads: what the two share -- the PairRec, the window's name base, the digits of the
+  // name -- is fetched and made once.
   // The reads' 48-byte rows leave through LDS: written by their lanes (16 bytes and single characters at a stride of 48:
-  // straight to memory every store instruction touched 64 cache lines), stored by the wave as 3 KB in one piece.
+  // straight to memory every store instruction touched 64 cache lines), stored by the wave as 3 KB in one piece; mate 2's
+  // rows reuse the space (its rows differ from mate 1's in the middle 16 bytes and in one character).
   __shared__ uint4 row_lds[256 * 3];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t m = blockIdx.y;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint4* const wave_rows = row_lds + (threadIdx.x & ~63u) * 3u;
+  // reads with at least one indel candidate (16 % at XTen rates), as local index | mate << 8, and what their walk found:
+  // {events, length change}, first event.  A wave in which every lane walks its own read's candidates pays for its
+  // unluckiest lane with most lanes idle; the listed reads are walked 64 to a wave instead.
+  __shared__ uint16_t cand[512];
+  __shared__ uint32_t cand_n;
+  __shared__ uint2 found[2][256];
+  __shared__ uint32_t found_first[2][256];
+  __shared__ uint32_t wave_len[2][4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t t = blockIdx.x * blockDim.x + tid;
+  const uint32_t nm = B.paired ? 2u : 1u;
+  uint4* const wave_rows = row_lds + (tid & ~63u) * 3u;
   uint4* const my_row = wave_rows + lane * 3u;
   const uint32_t t_wave = t - lane;  // the wave's first slot
-  auto store_rows = [&]() {
-    wave_lds_sync();
-    uint4* dst = B.meta + ((size_t)m * B.n_slots + t_wave) * 3;
-    const uint32_t n_pieces = min(B.n_slots - t_wave, 64u) * 3u;  // 16-byte pieces of the wave's rows that exist
-#pragma unroll
-    for (uint32_t i = 0; i < 3u; i++) {
-      const uint32_t q = i * 64u + lane;
-      if (q < n_pieces) dst[q] = wave_rows[q];
-    }
-  };
-  // the table of the indel distances (see below), staged by the whole block before any wave can leave
+  // the table of the indel distances (see below), staged by the whole block
   __shared__ uint64_t gap_lds[256];
   const uint64_t* gap = P.gap_row;
   if ((uint32_t)P.L + 1u <= 256u) {  // (longer reads: from L2)
-    for (uint32_t i = threadIdx.x; i <= (uint32_t)P.L; i += blockDim.x) gap_lds[i] = P.gap_row[i];
+    for (uint32_t i = tid; i <= (uint32_t)P.L; i += blockDim.x) gap_lds[i] = P.gap_row[i];
     gap = gap_lds;
-    __syncthreads();
   }
+  if (tid == 0u) cand_n = 0u;
   const bool in_batch = t < B.n_slots;
-  const size_t idx = (size_t)m * B.n_slots + (in_batch ? t : 0u);
   PairRec rec = {};
   if (in_batch) rec = B.pairs[t];
   const uint32_t flen = rec.fl & 0x7FFFFFFFu;
-  uint32_t rl = 0;  // the read's record length (0: nothing planned)
-  // Record offsets: exclusive prefix of the record lengths inside the block of 256 reads, here; the blocks' bases by
-  // one small kernel afterwards (block_base_kernel).  offset = base[block] + prefix (rec_offset()).
-  __shared__ uint32_t wave_len[4];
-  auto block_prefix = [&]() {
-    uint32_t incl = rl;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t up = __shfl_up(incl, d, 64);
-      if ((int)lane >= d) incl += up;
-    }
-    if (lane == 63u) wave_len[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t base = 0, all = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4u; i++) {
-      const uint32_t w = wave_len[i];
-      if (i < (threadIdx.x >> 6)) base += w;
-      all += w;
-    }
-    if (in_batch) B.recloc[idx] = base + incl - rl;
-    if (threadIdx.x == 0) B.blkbase[(size_t)m * gridDim.x + blockIdx.x] = all;
-  };
-  if (__ballot(flen != 0u) == 0ull) {  // nothing planned in the whole wave
-    my_row[0] = my_row[1] = my_row[2] = make_uint4(0, 0, 0, 0);
-    if (t_wave < B.n_slots) store_rows();
-    block_prefix();
-    return;
-  }
-  if (!flen) my_row[0] = my_row[1] = my_row[2] = make_uint4(0, 0, 0, 0);
-  // (lanes without a fragment stay in the kernel for the wave-wide steps below, doing nothing in between)
   const bool live = flen != 0u;
-  const int L = live ? P.L : 0;
-  int j = 0, dl = 0;
-  uint32_t nev = 0, first_ev = 0;
-  uint32_t* ev = B.events + idx * SG_MAX_EVENTS;
-  const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
+  const uint32_t L = (uint32_t)P.L;
+  // What the reads' rows need beyond the PairRec (plan_kernel put the window's part there), fetched before anything
+  // else: the window's name base and the bad-block bits, gathers whose latency the Philox calls below cover.
+  uint32_t fragcount = 0, touches_bad[2] = {0, 0};
+  const uint64_t foff = rec.foff;
+  const uint32_t rev1 = rec.fl >> 31;  // SE: the read's strand (PE: mate 1 forward, mate 2 reverse)
+  if (live) {
+    fragcount = B.win_namebase[rec.win] + rec.k + 1u;
+    // A read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
+    // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
+    // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
+    for (uint32_t m = 0; m < nm; m++) {
+      const bool rev = B.paired ? (m == 1u) : (rev1 != 0u);
+      const uint64_t t0 = (rev ? foff + flen - L : foff) - 8u, t1 = t0 + L + 24u;  // inside the guard bytes
+      uint32_t bad = 0;
+      for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
+      touches_bad[m] = bad;
+    }
+  }
+  __syncthreads();  // gap_lds, cand_n
   // Sequencing indels by skipping ahead (DevProfile::gap_row): every template position is an indel candidate with
   // probability evB / 2^64, independently, so the distance to the next one is geometric and is drawn directly -- call
   // (slot, e, 0) of the read's e-th candidate: x = words (1, 0) against the table P(no candidate in k positions),
   // y = words (3, 2): an insertion iff floor(y evB / 2^64) < evA.  A read without indels (84 % at XTen rates) costs ONE
   // call and ONE compare (x < gap[L]); testing every position took 19 calls per 151-base read.
-  // What the read's row needs beyond its PairRec (plan_kernel put the window's part there), fetched BEFORE the candidate
-  // loop: the window's name base and the bad-block bits, two gathers whose latency the loop's Philox calls then cover.
-  uint32_t namepos = 0, fragcount = 0, touches_bad = 0;
-  uint64_t foff = 0;
-  const uint32_t rev = B.paired ? (m == 1u) : (rec.fl >> 31);
-  if (live) {
-    namepos = rec.namepos;
-    fragcount = B.win_namebase[rec.win] + rec.k + 1u;
-    foff = rec.foff;
-    // The read's template is the first (forward) / last (reverse) L bases of the fragment; does it -- with the two context
-    // bases before it and the slack of the emit kernel's last item -- touch a 64-base block holding a non-ACGT base?
-    // Such reads go through the generic item code (the straight-line kernel reads 2-bit codes).
-    const uint64_t t0 = (rev ? foff + flen - (uint32_t)L : foff) - 8u, t1 = t0 + (uint32_t)L + 24u;  // inside the guard bytes
-    for (uint64_t b = t0 >> 6; b <= (t1 >> 6); b++) touches_bad |= (B.chains_bad[b >> 4] >> (b & 15u)) & 1u;
-  }
-  {
-    uint32_t e = 0;
-#pragma unroll 1
-    while (j < L) {  // (L = 0 for lanes without a fragment)
+  for (uint32_t m = 0; m < nm; m++) {
+    found[m][tid] = make_uint2(0u, 0u);
+    found_first[m][tid] = 0u;
+    bool has = false;
+    if (live) {
       uint32_t x4[4];
-      philox4x32_10(t + B.slot_offset, e++, 0, c3, B.k0, B.k1, x4);
-      const uint64_t x = ((uint64_t)x4[1] << 32) | x4[0], y = ((uint64_t)x4[3] << 32) | x4[2];
-      const int room = L - j;
-      if (x < gap[room]) break;                 // no candidate before the read's end
-      int lo = 0, hi = room - 1;                // g = #{k in [1, room): x < gap[k]} (gap decreases)
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (x < gap[mid]) lo = mid; else hi = mid - 1;
+      philox4x32_10(t + B.slot_offset, 0u, 0, dev_ctx(KIND_INDEL, m, B.batch_id), B.k0, B.k1, x4);
+      const uint64_t x = ((uint64_t)x4[1] << 32) | x4[0];
+      has = !(x < gap[L]);
+    }
+    const unsigned long long hm = __ballot(has);
+    if (hm) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__builtin_ctzll(hm)) base = atomicAdd(&cand_n, (uint32_t)__popcll(hm));
+      base = __shfl(base, __builtin_ctzll(hm), 64);
+      if (has) cand[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint16_t)(tid | (m << 8));
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t nc = cand_n;
+#pragma unroll 1
+    for (uint32_t i = tid; i < nc; i += blockDim.x) {
+      const uint32_t e16 = cand[i], lt = e16 & 255u, m = e16 >> 8;
+      const uint32_t tt = blockIdx.x * blockDim.x + lt;
+      uint32_t* ev = B.events + ((size_t)m * B.n_slots + tt) * SG_MAX_EVENTS;
+      const uint32_t c3 = dev_ctx(KIND_INDEL, m, B.batch_id);
+      int j = 0, dl = 0;
+      uint32_t nev = 0, first_ev = 0, e = 0;
+#pragma unroll 1
+      while (j < (int)L) {
+        uint32_t x4[4];
+        philox4x32_10(tt + B.slot_offset, e++, 0, c3, B.k0, B.k1, x4);
+        const uint64_t x = ((uint64_t)x4[1] << 32) | x4[0], y = ((uint64_t)x4[3] << 32) | x4[2];
+        const int room = (int)L - j;
+        if (x < gap[room]) break;                 // no candidate before the read's end
+        int lo = 0, hi = room - 1;                // g = #{k in [1, room): x < gap[k]} (gap decreases)
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (x < gap[mid]) lo = mid; else hi = mid - 1;
+        }
+        const int jj = j + lo;
+        const bool is_ins = __umul64hi(y, P.evB) < P.evA;
+        j = jj + 1;
+        if (is_ins) {
+          uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, tt, (uint32_t)jj, 0, m));
+          if (len > 0) {
+            if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, len, 0);
+            if (nev == 0) first_ev = ev_pack((uint32_t)jj, len, 0);
+            nev++;
+            dl += (int)len;
+          }
+        } else {
+          uint32_t len = row_search(P.del_row, P.del_lg, aux_draw(B, tt, (uint32_t)jj, 0, m));
+          if (len > 0) {
+            uint32_t k = min((uint32_t)((int)L - jj), len);
+            if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, k, 1);
+            if (nev == 0) first_ev = ev_pack((uint32_t)jj, k, 1);
+            nev++;
+            dl -= (int)k;
+            j = jj + (int)k;
+          }
+        }
       }
-      const int jj = j + lo;
-      const bool is_ins = __umul64hi(y, P.evB) < P.evA;
-      j = jj + 1;
-      if (is_ins) {
-        uint32_t len = row_search(P.ins_row, P.ins_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
-        if (len > 0) {
-          if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, len, 0);
-          if (nev == 0) first_ev = ev_pack((uint32_t)jj, len, 0);
-          nev++;
-          dl += (int)len;
-        }
-      } else {
-        uint32_t len = row_search(P.del_row, P.del_lg, aux_draw(B, t, (uint32_t)jj, 0, m));
-        if (len > 0) {
-          uint32_t k = min((uint32_t)(L - jj), len);
-          if (nev < SG_MAX_EVENTS) ev[nev] = ev_pack((uint32_t)jj, k, 1);
-          if (nev == 0) first_ev = ev_pack((uint32_t)jj, k, 1);
-          nev++;
-          dl -= (int)k;
-          j = jj + (int)k;
-        }
+      found[m][lt] = make_uint2(nev, (uint32_t)dl);
+      found_first[m][lt] = first_ev;
+    }
+  }
+  __syncthreads();
+  // ---- the reads' rows, their record lengths and the prefix of those inside the block ----
+  // Per-read 48-byte row for the emit kernels: m0 = fragment offset + the two numbers of the read's name
+  // "@popu#chr#pos%segsize#fragCount[/m]" (Segment.cpp:780,809,824), m1 = lengths, reciprocal, event, then the
+  // name's own part "pos#count[/m]\n" as text when it fits 16 bytes (emit_fast_kernel stores it behind the batch's
+  // constant prefix; this kernel has the VALU time for the digits, that one has not).
+  const uint32_t namepos = rec.namepos;
+  const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
+  uint32_t mate_at = 0;  // where the name's mate digit sits in the text
+  my_row[0] = live ? make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount) : make_uint4(0, 0, 0, 0);
+  my_row[2] = make_uint4(0, 0, 0, 0);
+  if (live && hdr - B.prefix_len <= 16u) {
+    uint8_t* hb = (uint8_t*)(my_row + 2);
+    uint32_t o = 0;
+    auto put_dec = [&](uint32_t v) {  // the digits of a number from its last one backwards
+      const uint32_t nd = ndigits(v);
+      for (uint32_t k = nd; k-- > 0u;) {
+        const uint32_t qd = v / 10u;
+        hb[o + k] = (uint8_t)('0' + (v - qd * 10u));
+        v = qd;
+      }
+      o += nd;
+    };
+    put_dec(namepos);
+    hb[o++] = '#';
+    put_dec(fragcount);
+    if (B.paired) { hb[o++] = '/'; mate_at = o; hb[o++] = '1'; }
+    hb[o] = '\n';
+  }
+  uint32_t rl[2] = {0, 0};
+  for (uint32_t m = 0; m < nm; m++) {
+    if (m == 1u) {
+      wave_lds_sync();  // mate 1's rows have been read
+      if (mate_at) ((uint8_t*)(my_row + 2))[mate_at] = '2';
+    }
+    uint4 mid = make_uint4(0, 0, 0, 0);
+    if (live) {
+      const uint2 f = found[m][tid];
+      uint32_t nev = f.x;
+      int dl = (int)f.y;
+      if ((int)L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
+      if (nev > SG_MAX_EVENTS) { atomicOr((unsigned long long*)&B.totals[3], 1ull); nev = 0; dl = 0; }
+      const uint32_t np = (uint32_t)((int)L + dl);
+      rl[m] = hdr + 2u * np + 4u;
+      const uint32_t rev = B.paired ? m : rev1;
+      // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
+      // (sg_load_profile rejects profiles that could violate the bound)
+      // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
+      mid = make_uint4(flen | (touches_bad[m] << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
+                       nev == 1u ? found_first[m][tid] : 0u);
+    }
+    my_row[1] = mid;
+    if (t_wave < B.n_slots) {
+      wave_lds_sync();
+      uint4* dst = B.meta + ((size_t)m * B.n_slots + t_wave) * 3;
+      const uint32_t n_pieces = min(B.n_slots - t_wave, 64u) * 3u;  // 16-byte pieces of the wave's rows that exist
+#pragma unroll
+      for (uint32_t i = 0; i < 3u; i++) {
+        const uint32_t q = i * 64u + lane;
+        if (q < n_pieces) dst[q] = wave_rows[q];
       }
     }
   }
-  if (live) {
-    if (L + dl < 50) { nev = 0; dl = 0; }  // Profile.cpp:1627-1634
-    if (nev > SG_MAX_EVENTS) { atomicOr((unsigned long long*)&B.totals[3], 1ull); nev = 0; dl = 0; }
-    const uint32_t np = (uint32_t)(L + dl);
-    const uint32_t hdr = B.prefix_len + ndigits(namepos) + 1u + ndigits(fragcount) + (B.paired ? 2u : 0u) + 1u;
-    rl = hdr + 2u * np + 4u;
-    // Per-read 48-byte row for the emit kernels: m0 = fragment offset + the two numbers of the read's name
-    // "@popu#chr#pos%segsize#fragCount[/m]" (Segment.cpp:780,809,824), m1 = lengths, reciprocal, event, then the
-    // name's own part "pos#count[/m]\n" as text when it fits 16 bytes (emit_fast_kernel stores it behind the batch's
-    // constant prefix; this kernel has the VALU time for the digits, that one has not).
-    my_row[0] = make_uint4((uint32_t)foff, (uint32_t)(foff >> 32), namepos, fragcount);
-    // ceil(2^32 / np) = floor((2^32-1)/np) + 1: bin = (i*bins*inv) >> 32 is exact while i*bins*np < 2^32
-    // (sg_load_profile rejects profiles that could violate the bound)
-    // m1.w: the event itself for single-event reads (handled inline by the emit kernel)
-    my_row[1] = make_uint4(flen | (touches_bad << 30) | (rev << 31), np | (nev << 16) | (hdr << 22), 0xFFFFFFFFu / np + 1u,
-                                     nev == 1u ? first_ev : 0u);
-    my_row[2] = make_uint4(0, 0, 0, 0);
-    if (hdr - B.prefix_len <= 16u) {
-      uint8_t* hb = (uint8_t*)(my_row + 2);
-      uint32_t o = 0;
-      auto put_dec = [&](uint32_t v) {  // the digits of a number from its last one backwards
-        const uint32_t nd = ndigits(v);
-        for (uint32_t k = nd; k-- > 0u;) {
-          const uint32_t qd = v / 10u;
-          hb[o + k] = (uint8_t)('0' + (v - qd * 10u));
-          v = qd;
-        }
-        o += nd;
-      };
-      put_dec(namepos);
-      hb[o++] = '#';
-      put_dec(fragcount);
-      if (B.paired) { hb[o++] = '/'; hb[o++] = (uint8_t)('1' + m); }
-      hb[o] = '\n';
+  // Record offsets: exclusive prefix of the record lengths inside the block of 256 reads, here; the blocks' bases by
+  // one small kernel afterwards (block_base_kernel).  offset = base[block] + prefix (rec_offset()).
+  uint32_t incl[2];
+  for (uint32_t m = 0; m < nm; m++) {
+    uint32_t v = rl[m];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(v, d, 64);
+      if ((int)lane >= d) v += up;
     }
+    incl[m] = v;
+    if (lane == 63u) wave_len[m][wv] = v;
   }
-  store_rows();
-  block_prefix();
+  __syncthreads();
+  for (uint32_t m = 0; m < nm; m++) {
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+      const uint32_t w = wave_len[m][i];
+      if (i < wv) base += w;
+      all += w;
+    }
+    if (in_batch) B.recloc[(size_t)m * B.n_slots + t] = base + incl[m] - rl[m];
+    if (tid == 0u) B.blkbase[(size_t)m * gridDim.x + blockIdx.x] = all;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1939,8 +1988,7 @@ void launch_namebase(const DevBatch& B, hipStream_t s) {
 }
 void launch_indel(const DevProfile& P, const DevBatch& B, hipStream_t s) {
   if (!B.n_slots) return;
-  dim3 grid((B.n_slots + 255) / 256, B.paired ? 2 : 1);
-  hipLaunchKernelGGL(indel_kernel, grid, dim3(256), 0, s, P, B);
+  hipLaunchKernelGGL(indel_kernel, dim3((B.n_slots + 255) / 256), dim3(256), 0, s, P, B);
 }
 bool emit_uses_fast_kernel(const DevProfile& P, const DevBatch& B);
 void launch_header(const DevProfile& P, const DevBatch& B, hipStream_t s) {
