@@ -1233,9 +1233,10 @@ __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code
 #define OVF_CAP 192   // per-wave list of single items: the plain reads' last items (<= 63) + appended items (<= 126)
 #define FIX_CAP 128   // per-wave list of flagged bases waiting for the group's fix-up pass
+#define CLEAN_CAP 256 // per-wave list of the one-indel reads' clean items (~10 such reads of 19 items in a group at XTen rates)
 
 template <bool PAIRED, bool DIAG>
-__global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t TI, uint32_t inv_TI) {
+__global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, DevBatch B, uint32_t TI, uint32_t inv_TI, uint32_t clean_cap) {
   extern __shared__ uint4 smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t m = blockIdx.y;
@@ -1260,6 +1261,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint8_t* perm_all = (uint8_t*)(fix_all + EMIT_WAVES * FIX_CAP);
   uint8_t* permp_all = perm_all + EMIT_WAVES * 64;                  // the plain reads of a group, in lane order
   uint16_t* ovf_all = (uint16_t*)(permp_all + EMIT_WAVES * 64);     // single items of the general stream (read | item << 8)
+  uint16_t* clean_all = ovf_all + EMIT_WAVES * OVF_CAP;             // clean items of one-indel reads (read | after << 6 | item << 7)
   {
     const uint4* src = (const uint4*)(P.fast_lds + (size_t)tm * P.fast_mate_words);  // 16-byte aligned on the host
     for (uint32_t i = tid; i < (img_words + 3u) / 4u; i += EMIT_THREADS) ((uint4*)img)[i] = src[i];
@@ -1287,6 +1289,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   uint8_t* perm = perm_all + wv * 64;
   uint8_t* permp = permp_all + wv * 64;
   uint16_t* ovf = ovf_all + wv * OVF_CAP;
+  uint16_t* clean = clean_all + wv * clean_cap;
   // Items per plain read that run through the plain steps: all but the last one, whose store is partial and followed by the
   // record separators -- unless the last item holds seven bases (L % 8 == 7, the 151-base profile): with the line break as
   // its eighth byte it is a whole item like the others, plus the two bytes of the "+" line.  (No fewer instructions that
@@ -1466,20 +1469,60 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     //    those with several, so that the two-window code and the event-list walk run in few steps), then single items: the
     //    plain reads' last items (partial or followed by the separators: the per-read pass and the parked-item logic
     //    belong to the general code) and the one or two items an insertion appended to a read.
+    //  * CLEAN steps: a read with ONE sequencing indel is, item by item, a plain read nearly everywhere -- the items wholly
+    //    before the event read the template unshifted, those wholly after it read it shifted by the event's length; what
+    //    differs from a plain item is the bin arithmetic (n' != L: no look-up row) and that shift.  Only the one to
+    //    three items the event reaches into, and the last, partial one, need the general code.  (Measured before this
+    //    split, SQ_INSTS_VALU with either loop compiled out: the general steps took 34 % of the kernel's instructions for
+    //    16 % of the reads -- every item of a one-indel read paid the two-window code and its insertion loop.)
     const uint32_t nev_l = (my1.y >> 16) & 0x3Fu;
     const uint32_t np_l = my1.y & 0xFFFFu;
     const bool act_l = items > 0u;
     const bool plain_l = act_l && nev_l == 0u && np_l == (uint32_t)P.L && items == TI && !((my1.x >> 30) & 1u) && TIp != 0u;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // one-indel reads: item ranges.  fc = first output position that is not the unshifted template's, fs = first one that
+    // reads the shifted template (an insertion's own bases lie between the two); an item's codes span positions
+    // 8c - 5 .. 8c + 7
+    uint32_t kb = 0, ca0 = 0, n_whole = 0, ka = 0, n_gen = 0, vscan = 0;
+    bool split_l = false;
+    if (clean_cap) {
+      const uint32_t ew = my1.w;
+      const uint32_t ej = ew & 0xFFFFu, elen = (ew >> 16) & 0x7FFFu;
+      const bool del = (ew >> 31) != 0u;
+      const uint32_t fc = del ? ej : ej + 1u, fs = del ? ej : ej + elen + 1u;
+      n_whole = np_l >> 3;
+      kb = min(fc >> 3, n_whole);                 // items 0 .. kb-1: wholly before
+      ca0 = (fs + 12u) >> 3;                      // items ca0 .. n_whole-1: wholly after (8c - 5 >= fs)
+      ka = n_whole > ca0 ? n_whole - ca0 : 0u;
+      n_gen = ka ? (ca0 - kb) + (items - n_whole) : items - kb;   // what is left for the general steps
+      const bool cand_l = act_l && nev_l == 1u && !((my1.x >> 30) & 1u) && items <= 255u && kb + ka != 0u;
+      // as many of them, in lane order, as the two lists hold (behind the other single items, counted below)
+      uint32_t v = cand_l ? ((kb + ka) << 16) | n_gen : 0u;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v += up;
+      }
+      vscan = v;   // (clean items << 16 | general items) of the candidates up to and including this lane
+      const uint32_t extra_l = items > TI ? items - TI : 0u;
+      const uint32_t others = (tail_whole ? 0u : (uint32_t)__popcll(__ballot(plain_l))) +
+                              (uint32_t)__popcll(__ballot(extra_l == 1u || extra_l == 2u)) + (uint32_t)__popcll(__ballot(extra_l == 2u));
+      split_l = cand_l && (v >> 16) <= clean_cap && others + (v & 0xFFFFu) <= OVF_CAP;
+      // (a prefix in lane order: the sums only grow)
+      kb = split_l ? kb : 0u;
+      ka = split_l ? ka : 0u;
+      n_gen = split_l ? n_gen : 0u;
+    }
+    const unsigned long long m_split = __ballot(split_l);
     const unsigned long long m_plain = __ballot(plain_l);
     const unsigned long long m_multi = __ballot(act_l && nev_l >= 2u);
-    const unsigned long long m_one = __ballot(act_l && nev_l == 1u);
+    const unsigned long long m_one = __ballot(act_l && nev_l == 1u && !split_l);
     const unsigned long long m_rest = __ballot(act_l && !plain_l && nev_l == 0u);
     const uint32_t n_plain = (uint32_t)__popcll(m_plain);
     const uint32_t n_psingle = tail_whole ? 0u : n_plain;   // plain reads' last items left to the general steps
     const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_one = (uint32_t)__popcll(m_one);
     const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // reads whose items all walk the general steps
-    if (act_l) {
+    if (act_l && !split_l) {
       if (plain_l) {
         const uint32_t pos = (uint32_t)__popcll(m_plain & lt);
         permp[pos] = (uint8_t)lane;
@@ -1496,7 +1539,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to the end of
     // the stream (they fill lanes of the last step that would idle anyway); only reads longer than that take
     // steps of their own below.
-    const uint32_t extra = items > TI ? items - TI : 0u;
+    const uint32_t extra = (items > TI && !split_l) ? items - TI : 0u;
     const bool small = extra == 1u || extra == 2u;
     const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
     if (small) {
@@ -1504,12 +1547,30 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       ovf[o] = (uint16_t)(lane | (TI << 8));
       if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
     }
-    const uint32_t n_ovf = n_psingle + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-    unsigned long long more = __ballot(extra > 2u);
+    uint32_t n_ovf = n_psingle + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    uint32_t n_clean = 0;
+    if (m_split) {
+      // the split reads' items into the two lists, each lane its own ranges (the split reads are the first candidates in
+      // lane order: the scan above holds their offsets)
+      const uint32_t tot = (uint32_t)__shfl((int)vscan, 63 - __builtin_clzll(m_split), 64);
+      uint32_t oc = (vscan >> 16) - (kb + ka), og = n_ovf + (vscan & 0xFFFFu) - n_gen;
+      if (split_l) {
+        // (one loop over both ranges: the wave runs as many iterations as its longest lane needs, and every split read has
+        // about TI - 2 clean items however they fall before and after its indel)
+        const uint32_t kt = kb + ka, behind = ((ca0 - kb) << 7) | 64u;
+        for (uint32_t k = 0; k < kt; k++) clean[oc + k] = (uint16_t)((lane | (k << 7)) + (k >= kb ? behind : 0u));
+        const uint32_t mid_end = ka ? ca0 : items;
+        for (uint32_t c = kb; c < mid_end; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
+        if (ka) for (uint32_t c = n_whole; c < items; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
+      }
+      n_clean = tot >> 16;
+      n_ovf += tot & 0xFFFFu;
+    }
+    unsigned long long more = (dg & 256u) ? 0ull : __ballot(extra > 2u);
     wave_lds_sync();
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
-    const uint32_t nmain = (n_stream + 63u) / 64u;
-    const uint32_t n_pitems = n_plain * TIp, npsteps = (n_pitems + 63u) / 64u;
+    const uint32_t nmain = (dg & 256u) ? 0u : (n_stream + 63u) / 64u;   // (ablations: no general / no plain steps)
+    const uint32_t n_pitems = n_plain * TIp, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
     // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
@@ -1653,6 +1714,77 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         const PStage nxt = fetch_plain(min(step + 1u, npsteps - 1u));
         run_plain(cur);
         cur = nxt;
+      }
+    }
+    // ---- clean steps: the plain step with the read's own bins, length and (behind the indel) shifted template ----
+    if (n_clean) {
+      const uint32_t ncsteps = (dg & 128u) ? 0u : (n_clean + 63u) / 64u;
+      struct CStage { uint32_t r, c, src, out, np, inv; bool ok; uint2 w; };
+      auto fetch_clean = [&](uint32_t step) -> CStage {
+        CStage st;
+        const uint32_t i_raw = step * 64u + lane;
+        st.ok = i_raw < n_clean;
+        const uint32_t e = clean[min(i_raw, n_clean - 1u)];   // idle lanes redo the list's last item, their stores are dropped
+        st.r = e & 63u;
+        st.c = e >> 7;
+        const uint4 q0 = meta_rows[st.r * 2], q1 = meta_rows[st.r * 2 + 1];
+        const uint32_t elen = (q1.w >> 16) & 0x7FFFu;
+        const uint32_t delta = (e & 64u) ? ((q1.w >> 31) ? elen : 0u - elen) : 0u;
+        st.src = (q0.y & 0x7FFFFFFFu) + 8u * st.c + delta;
+        st.out = q0.w + 8u * st.c;
+        st.np = q1.y & 0xFFFFu;
+        st.inv = q1.z;
+        const uint8_t* copy2 = (PAIRED ? m == 1u : (q0.y >> 31) != 0u) ? B.chains2_rc : B.chains2_fwd;
+        __builtin_memcpy(&st.w, copy2 + (st.src >> 2), 8);
+        return st;
+      };
+      const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+      const uint32_t lgW = P.lgW, blk_bytes = P.fast_stride * 4u;
+      auto run_clean = [&](const CStage& st) {
+        const uint32_t c = st.c;
+        uint32_t cw;
+        if (dg & 4u) cw = (g * G + st.r) * 2654435761u + c;  // ablation: no haplotype fetch
+        else cw = (uint32_t)((((uint64_t)st.w.y << 32) | st.w.x) >> (2u * (st.src & 3u)));
+        uint32_t x[8];
+        const uint32_t slot = g * G + st.r + B.slot_offset;
+        if (dg & 8u) {  // ablation: no Philox
+#pragma unroll
+          for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
+        } else {
+          philox_base(slot, 2u * c, 0, c3b, B.k0, B.k1, x);
+          philox_base(slot, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+        }
+        // bin = i * binCount / n' (Profile.cpp:1672) by the row's reciprocal
+        uint32_t so[8];
+        const uint32_t ib0 = __umul24(8u * c, bins);
+#pragma unroll
+        for (int h = 0; h < 8; h++) so[h] = __umul24(__umulhi(ib0 + (uint32_t)h * bins, st.inv), blk_bytes);
+        const uint32_t qo0 = so[0], qo1 = so[1];
+        if (c == 0u) { so[0] += 128u * 4u; so[1] += 64u * 4u; }
+        uint32_t sw[2], qw[2], acc;
+        sample8(img, code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
+        const bool st_ok = st.ok && !(dg & 1u);
+        const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
+        const uint32_t qo_ = st_ok ? st.out + st.np + 3u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, so_, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, qo_, 0, 0);
+        const uint32_t fix = (st.ok && !(dg & 16u)) ? (acc >> 17) & 0xFFu : 0u;
+        const unsigned long long fm = __ballot(fix != 0u);
+        if (fm) {
+          if (nfix + 64u > FIX_CAP) flush_fix();
+          if (fix != 0u) fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(st.r | (fix << 6) | (c << 17), cw);
+          nfix += (uint32_t)__popcll(fm);
+        }
+      };
+      if (ncsteps) {
+        CStage cur = fetch_clean(0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
+        for (uint32_t step = 0; step < ncsteps; step++) {
+          const CStage nxt = fetch_clean(min(step + 1u, ncsteps - 1u));
+          run_clean(cur);
+          cur = nxt;
+        }
       }
     }
     // ---- general steps ----
@@ -2085,9 +2217,14 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     if (fgx > fneed) fgx = fneed;
     const dim3 fgrid(fgx, nm);
     const uint32_t inv_TI = (1u << 20) / TIf + 1u;
+    // the list of the one-indel reads' clean items, where the table image leaves room for it (else those reads stay whole
+    // in the general steps: same output)
+    const size_t clean_b = (size_t)EMIT_WAVES * CLEAN_CAP * 2;
+    const uint32_t clean_cap = getenv("SG_NO_CLEAN_STEPS") == nullptr && e.lds_fast + clean_b <= kLdsBytes ? CLEAN_CAP : 0u;
+    const size_t lds_fast = e.lds_fast + (clean_cap ? clean_b : 0);
     auto launch_fast = [&](auto kern) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e.lds_fast);
-      hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), e.lds_fast, s, P, B, TIf, inv_TI);
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+      hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), lds_fast, s, P, B, TIf, inv_TI, clean_cap);
     };
     if (B.diag) {  // timing ablations (SG_FDIAG)
       if (B.paired) launch_fast(emit_fast_kernel<true, true>);
