@@ -1120,6 +1120,7 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 
   // reads with exactly one sequencing indel: past the event the window is shifted by +-len
   if (__ballot(nev == 1u) != 0ull) {
+    int q_ins = 1, q_end = 0;  // an insertion's own positions inside the item's window
     if (nev == 1u) {
       const uint32_t ew = ew_in;
       const int ej = (int)(ew & 0xFFFFu), elen = (int)((ew >> 16) & 0x7FFFu);
@@ -1133,17 +1134,18 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
       if (!del) {
         // inserted run = output positions ej+1 .. ej+elen: randomInteger(0, N-1), never the last base
         // (Profile.cpp:1564); flat draw f = p - ej of stream (slot, ej); codes are `bases` indexes
+        // (window indexes q = p - (i0 - 5) in 3 .. 12 of those positions; the wave loops as often as its longest run needs)
+        q_ins = max(3, ej + 1 - ((int)i0 - 5));
+        q_end = min(12, ej + elen - ((int)i0 - 5));
+      }
+    }
 #pragma unroll 1
-        for (int q = 3; q < 13; q++) {
-          const int p = (int)i0 - 5 + q;
-          const bool ins = p > ej && p <= ej + elen;
-          if (__ballot(ins) == 0ull) continue;
-          if (ins) {
-            const uint32_t prof = __umulhi(aux_draw(B, slot, tj_in, (uint32_t)(p - ej), m), 3u);
-            const uint32_t nat = (P.inv_remap_packed >> (2u * prof)) & 3u;
-            cw = (cw & ~(3u << (2 * q))) | (nat << (2 * q));
-          }
-        }
+    for (; __ballot(q_ins <= q_end) != 0ull; q_ins++) {
+      if (q_ins <= q_end) {
+        const int p = (int)i0 - 5 + q_ins, ej = (int)(ew_in & 0xFFFFu);
+        const uint32_t prof = __umulhi(aux_draw(B, slot, tj_in, (uint32_t)(p - ej), m), 3u);
+        const uint32_t nat = (P.inv_remap_packed >> (2u * prof)) & 3u;
+        cw = (cw & ~(3u << (2 * q_ins))) | (nat << (2 * q_ins));
       }
     }
   }
@@ -1522,11 +1524,31 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     const uint32_t n_psingle = tail_whole ? 0u : n_plain;   // plain reads' last items left to the general steps
     const uint32_t n_rest = (uint32_t)__popcll(m_rest), n_one = (uint32_t)__popcll(m_one);
     const uint32_t n_fast = n_rest + n_one + (uint32_t)__popcll(m_multi);  // reads whose items all walk the general steps
+    // TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to the end of
+    // the stream (they fill lanes of the last step that would idle anyway); only reads longer than that take
+    // steps of their own below.
+    const uint32_t extra = (items > TI && !split_l) ? items - TI : 0u;
+    const bool small = extra == 1u || extra == 2u;
+    const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
+    const uint32_t n_single = n_psingle + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    // the split reads' totals (they are the first candidates in lane order: the scan above holds their sums and offsets)
+    const uint32_t tot = m_split ? (uint32_t)__shfl((int)vscan, 63 - __builtin_clzll(m_split), 64) : 0u;
+    uint32_t n_clean = tot >> 16;
+    const uint32_t n_gen_all = tot & 0xFFFFu;
+    // The clean list's last, partial step: if the general stream's last step has that many idle lanes, the items go there
+    // as single items (the general code does them as well) and the step is saved.  They go FIRST among the single items:
+    // a read's last item is parked in its LDS row over fields its other items need (fast_item), so nothing of a read may
+    // follow its last item in the stream.
+    uint32_t n_moved = 0;
+    {
+      const uint32_t rem = n_clean & 63u, idle = (0u - (n_fast * TI + n_single + n_gen_all)) & 63u;
+      if (rem != 0u && rem <= idle && n_single + n_gen_all + rem <= OVF_CAP) n_moved = rem;
+    }
     if (act_l && !split_l) {
       if (plain_l) {
         const uint32_t pos = (uint32_t)__popcll(m_plain & lt);
         permp[pos] = (uint8_t)lane;
-        if (!tail_whole) ovf[pos] = (uint16_t)(lane | (TIp << 8));   // its last item: a single item of the general stream
+        if (!tail_whole) ovf[n_moved + pos] = (uint16_t)(lane | (TIp << 8));   // its last item: a single item of the general stream
       } else {
         uint32_t pos;
         if ((m_rest >> lane) & 1ull) pos = (uint32_t)__popcll(m_rest & lt);
@@ -1536,38 +1558,34 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       }
     }
     if (n_fast == 0u && lane == 0u) perm[0] = 0;   // (what idle lanes of a step look at)
-    // TI = ceil(L / 8) exactly; a read that an insertion grew by one or two items appends them to the end of
-    // the stream (they fill lanes of the last step that would idle anyway); only reads longer than that take
-    // steps of their own below.
-    const uint32_t extra = (items > TI && !split_l) ? items - TI : 0u;
-    const bool small = extra == 1u || extra == 2u;
-    const unsigned long long b1 = __ballot(small), b2 = __ballot(extra == 2u);
     if (small) {
-      const uint32_t o = n_psingle + (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+      const uint32_t o = n_moved + n_psingle + (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
       ovf[o] = (uint16_t)(lane | (TI << 8));
       if (extra == 2u) ovf[o + 1u] = (uint16_t)(lane | ((TI + 1u) << 8));
     }
-    uint32_t n_ovf = n_psingle + (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-    uint32_t n_clean = 0;
-    if (m_split) {
-      // the split reads' items into the two lists, each lane its own ranges (the split reads are the first candidates in
-      // lane order: the scan above holds their offsets)
-      const uint32_t tot = (uint32_t)__shfl((int)vscan, 63 - __builtin_clzll(m_split), 64);
-      uint32_t oc = (vscan >> 16) - (kb + ka), og = n_ovf + (vscan & 0xFFFFu) - n_gen;
-      if (split_l) {
-        // (one loop over both ranges: the wave runs as many iterations as its longest lane needs, and every split read has
-        // about TI - 2 clean items however they fall before and after its indel)
-        const uint32_t kt = kb + ka, behind = ((ca0 - kb) << 7) | 64u;
-        for (uint32_t k = 0; k < kt; k++) clean[oc + k] = (uint16_t)((lane | (k << 7)) + (k >= kb ? behind : 0u));
-        const uint32_t mid_end = ka ? ca0 : items;
-        for (uint32_t c = kb; c < mid_end; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
-        if (ka) for (uint32_t c = n_whole; c < items; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
-      }
-      n_clean = tot >> 16;
-      n_ovf += tot & 0xFFFFu;
+    if (split_l) {
+      // the split reads' items into the two lists, each lane its own ranges (one loop over both clean ranges: the wave runs
+      // as many iterations as its longest lane needs, and every split read has about TI - 2 clean items however they fall
+      // before and after its indel)
+      const uint32_t oc = (vscan >> 16) - (kb + ka);
+      uint32_t og = n_moved + n_single + (vscan & 0xFFFFu) - n_gen;
+      const uint32_t kt = kb + ka, behind = ((ca0 - kb) << 7) | 64u;
+      for (uint32_t k = 0; k < kt; k++) clean[oc + k] = (uint16_t)((lane | (k << 7)) + (k >= kb ? behind : 0u));
+      const uint32_t mid_end = ka ? ca0 : items;
+      for (uint32_t c = kb; c < mid_end; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
+      if (ka) for (uint32_t c = n_whole; c < items; c++) ovf[og++] = (uint16_t)(lane | (c << 8));
     }
+    const uint32_t n_ovf = n_moved + n_single + n_gen_all;
     unsigned long long more = (dg & 256u) ? 0ull : __ballot(extra > 2u);
     wave_lds_sync();
+    if (n_moved) {
+      n_clean -= n_moved;
+      if (lane < n_moved) {
+        const uint32_t e = clean[n_clean + lane];
+        ovf[lane] = (uint16_t)((e & 63u) | ((e >> 7) << 8));
+      }
+      wave_lds_sync();
+    }
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
     const uint32_t nmain = (dg & 256u) ? 0u : (n_stream + 63u) / 64u;   // (ablations: no general / no plain steps)
     const uint32_t n_pitems = n_plain * TIp, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
