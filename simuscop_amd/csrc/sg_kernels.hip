@@ -1031,34 +1031,48 @@ __device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h
 //   qo0/qo1 the plain bin offsets of positions 0 and 1
 // Out: sw = the eight called characters (= the reference bases), qw = the eight quality characters, acc bit 17 + h = the
 // head could not decide base h (possible substitution, or a head equal to a threshold's): the fix-up pass redoes it.
-__device__ __forceinline__ void sample8(const uint32_t* img, const uint32_t* code4, uint32_t lgW, uint32_t cw, const uint32_t (&x)[8],
+// one base of the block (see sample8)
+template <int H>
+__device__ __forceinline__ void sample1(uint32_t col_sh, uint32_t col_mask, uint32_t cw, uint32_t wh, uint32_t so_h, uint32_t qo_h, uint32_t cd4_w,
+                                        uint32_t& acc, uint32_t& sy) {
+  // so_h, qo_h are absolute LDS byte addresses (the image's own address is part of them: the look-up rows hold it, the
+  // arithmetic paths add it), read through integer-made LDS pointers: with a pointer base in the expression every
+  // address cost an instruction more (an add of the base, a constant the compiler only learns at link time)
+  typedef const __attribute__((address_space(3))) uint32_t* lds_word;
+  // substitution: sure "none" iff the 16-bit head (high half) is below the row's keep count: d_s = keep_h - 1 - head >= 0
+  const uint32_t kv4 = (cw >> (2 * H + 4)) & 0xFCu;   // the context's row word, as a byte offset
+  const uint32_t keepm1 = *(lds_word)(uintptr_t)(so_h + kv4);
+  const uint32_t d_s = keepm1 - (wh >> 16);
+  // quality: alias column (col, cd) of the diagonal row; its low half holds col : thr_head, so the draw's low half minus
+  // it is d_q = u_head - thr_head: negative -> lo, positive -> hi, zero -> the tail decides (fix-up)
+  // (column * 16 by a right shift and a mask: both issue at the full rate, a bit-field extract and a left shift do not)
+  const uint32_t col16 = (wh >> col_sh) & col_mask;
+  const uint32_t qa = qo_h + ((cd4_w >> (8 * (H & 3))) & 0xFFu);
+  const uint32_t e = *(lds_word)(uintptr_t)(qa + col16 + FAST_CTX * 4u);
+  const uint32_t d_q = (wh & 0xFFFFu) - (e & 0xFFFFu);
+  // flag (bits 17.. are copies of it): substitution possible (d_s < 0) or head on the threshold (d_q == 0)
+  const uint32_t z = __builtin_amdgcn_bitop3_b32(d_q - 1u, d_q, d_s, BITOP_ANDN_OR);
+  acc = __builtin_amdgcn_bitop3_b32(acc, z, 1u << (17 + H), BITOP_OR_AND);
+  // symbol = hi ^ ((lo ^ hi) & (d_q < 0)), fields at bits 24.. and 16..: lands in byte 2 (the image holds the symbols as
+  // characters: the profile's lowest quality character is added on the host)
+  sy = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
+}
+
+__device__ __forceinline__ void sample8(const uint32_t* code4, uint32_t lgW, uint32_t cw, const uint32_t (&x)[8],
                                         const uint32_t (&so)[8], uint32_t qo0, uint32_t qo1, uint32_t (&sw)[2], uint32_t (&qw)[2],
                                         uint32_t& acc_out) {
-  const uint8_t* img_b = (const uint8_t*)img;
   // the items's eight reference codes as bytes code * 4 (alias column offset, and >> 2 the character selector)
   const uint32_t cd4[2] = {code4[(cw >> 10) & 0xFFu], code4[(cw >> 18) & 0xFFu]};
-  const uint32_t col_at = 16u - lgW;
+  const uint32_t col_sh = 12u - lgW, col_mask = ((1u << lgW) - 1u) << 4;   // (lgW <= 7)
   uint32_t acc = 0, sy[8];
-#pragma unroll
-  for (int h = 0; h < 8; h++) {
-    const uint32_t wh = x[h];
-    // substitution: sure "none" iff the 16-bit head (high half) is below the row's keep count: d_s = keep_h - 1 - head >= 0
-    const uint32_t kv = __builtin_amdgcn_ubfe(cw, 2 * h + 6, 6);
-    const uint32_t keepm1 = *(const uint32_t*)(img_b + so[h] + (kv << 2));
-    const uint32_t d_s = keepm1 - (wh >> 16);
-    // quality: alias column (col, cd) of the diagonal row; its low half holds col : thr_head, so the draw's low half minus
-    // it is d_q = u_head - thr_head: negative -> lo, positive -> hi, zero -> the tail decides (fix-up)
-    const uint32_t col = __builtin_amdgcn_ubfe(wh, col_at, lgW);
-    const uint32_t qa = (h == 0 ? qo0 : h == 1 ? qo1 : so[h]) + ((cd4[h >> 2] >> (8 * (h & 3))) & 0xFFu);
-    const uint32_t e = *(const uint32_t*)(img_b + qa + (col << 4) + FAST_CTX * 4u);
-    const uint32_t d_q = (wh & 0xFFFFu) - (e & 0xFFFFu);
-    // flag (bits 17.. are copies of it): substitution possible (d_s < 0) or head on the threshold (d_q == 0)
-    const uint32_t z = __builtin_amdgcn_bitop3_b32(d_q - 1u, d_q, d_s, BITOP_ANDN_OR);
-    acc = __builtin_amdgcn_bitop3_b32(acc, z, 1u << (17 + h), BITOP_OR_AND);
-    // symbol = hi ^ ((lo ^ hi) & (d_q < 0)), fields at bits 24.. and 16..: lands in byte 2 (the image holds the symbols as
-    // characters: the profile's lowest quality character is added on the host)
-    sy[h] = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
-  }
+  sample1<0>(col_sh, col_mask, cw, x[0], so[0], qo0, cd4[0], acc, sy[0]);
+  sample1<1>(col_sh, col_mask, cw, x[1], so[1], qo1, cd4[0], acc, sy[1]);
+  sample1<2>(col_sh, col_mask, cw, x[2], so[2], so[2], cd4[0], acc, sy[2]);
+  sample1<3>(col_sh, col_mask, cw, x[3], so[3], so[3], cd4[0], acc, sy[3]);
+  sample1<4>(col_sh, col_mask, cw, x[4], so[4], so[4], cd4[1], acc, sy[4]);
+  sample1<5>(col_sh, col_mask, cw, x[5], so[5], so[5], cd4[1], acc, sy[5]);
+  sample1<6>(col_sh, col_mask, cw, x[6], so[6], so[6], cd4[1], acc, sy[6]);
+  sample1<7>(col_sh, col_mask, cw, x[7], so[7], so[7], cd4[1], acc, sy[7]);
   // byte 2 of four symbols words -> one word (selector bytes: 0-3 from the second operand, 4-7 from the first)
 #pragma unroll
   for (int g = 0; g < 2; g++) {
@@ -1083,7 +1097,7 @@ __device__ __forceinline__ uint32_t fast_src(const DevBatch& B, uint32_t m, cons
 }
 
 template <bool PAIRED, bool DIAG>
-__device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, const uint32_t* img, const uint32_t* lut,
+__device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B, uint32_t img_at, const uint32_t* lut,
                                           const uint32_t* code4, uint32_t TI, uint32_t m, const uint4 m0, const uint4 m1,
                                           uint32_t slot, uint32_t c, bool active, uint4* tail_row, int d0, uint32_t n_in,
                                           uint32_t ew_in, uint32_t tj_in, uint32_t src0, uint2 wpre,
@@ -1177,13 +1191,13 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
     for (int h = 0; h < 8; h++) {
       // idle lanes may compute a bin past the table: LDS reads beyond the allocation return 0, results unused
       const uint32_t bin = __umulhi(ib0 + (uint32_t)h * bins, inv);
-      so[h] = __umul24(active ? bin : 0u, blk_bytes);
+      so[h] = __umul24(active ? bin : 0u, blk_bytes) + img_at;
     }
     qo0 = so[0]; qo1 = so[1];
     if (c == 0u) { so[0] += 128u * 4u; so[1] += 64u * 4u; }
   }
   uint32_t qw[2], sw[2], acc;
-  sample8(img, code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
+  sample8(code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
   const bool slow = active && (bad != 0u || nev >= 2u);  // queued for the generic item code by the caller
   // flagged bases are redone exactly by the group's fix-up pass (the flags of a queued item do not matter)
   fix = (active && !slow && !(dg & 16u)) ? (acc >> 17) & 0xFFu & ((1u << min(8u, np - i0)) - 1u) : 0u;
@@ -1255,6 +1269,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   //           [per-wave read rows][slow-item queues][fix-up lists][read order][appended items] ----
   const uint32_t img_words = bins * P.fast_stride;
   uint32_t* img = (uint32_t*)smem;
+  const uint32_t img_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)img;  // its LDS byte address
   uint32_t* lut = img + ((img_words + 3u) & ~3u);
   uint32_t* code4 = lut + TI * LUT_ROW;
   uint4* lds_meta_all = (uint4*)(code4 + 256);
@@ -1276,7 +1291,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint32_t bin = min(pos * bins / (uint32_t)P.L, bins - 1u);
       uint32_t v = bin * blk_bytes;
       if (f < 8u && c == 0u) v += f == 0u ? 128u * 4u : f == 1u ? 64u * 4u : 0u;
-      lut[i] = f < 10u ? v : 0u;
+      lut[i] = f < 10u ? v + img_at : 0u;
     }
     for (uint32_t i = tid; i < 256u; i += EMIT_THREADS) {
       uint32_t v = 0;
@@ -1645,7 +1660,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         }
       }
       uint32_t fix, cw;
-      const bool slow = fast_item<PAIRED, DIAG>(P, B, img, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
+      const bool slow = fast_item<PAIRED, DIAG>(P, B, img_at, lut, code4, TI, m, m0, m1, g * G + r, c, active, meta_rows + r * 2, d0, n_in, ew_in,
                                           tj_in, st.src, st.w, out_rsrc, fix, cw);
       const unsigned long long sm = __ballot(slow);
       if (sm) {
@@ -1664,13 +1679,17 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // ---- plain steps ----
     if (npsteps) {
       struct PStage { uint32_t r, c, src, out; bool ok; uint2 w; };
+      // (three wave-uniform values of every step held in vector registers: as scalars they were spilled and came back
+      // through a v_readlane_b32 in every step)
+      uint32_t TIp_v = TIp, inv_TIp_v = inv_TIp, qual_at = (uint32_t)P.L + 3u;
+      asm volatile("" : "+v"(TIp_v), "+v"(inv_TIp_v), "+v"(qual_at));
       auto fetch_plain = [&](uint32_t step) -> PStage {
         PStage st;
         const uint32_t i_raw = step * 64u + lane;
         st.ok = i_raw < n_pitems;
         const uint32_t i = min(i_raw, n_pitems - 1u);     // idle lanes redo the stream's last item, their stores are dropped
-        const uint32_t ri = __umul24(i, inv_TIp) >> 20;  // i / TIp
-        st.c = i - __umul24(ri, TIp);
+        const uint32_t ri = __umul24(i, inv_TIp_v) >> 20;  // i / TIp
+        st.c = i - __umul24(ri, TIp_v);
         st.r = permp[ri];
         const uint32_t* row = (const uint32_t*)(meta_rows + st.r * 2);
         const uint32_t A = row[1];
@@ -1700,10 +1719,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         const uint4 r0 = lrow[0], r1 = lrow[1], r2 = lrow[2];
         const uint32_t so[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         uint32_t sw[2], qw[2], acc;
-        sample8(img, code4, lgW, cw, x, so, r2.x, r2.y, sw, qw, acc);
+        sample8(code4, lgW, cw, x, so, r2.x, r2.y, sw, qw, acc);
         const bool st_ok = st.ok && !(dg & 1u);
         const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
-        const uint32_t qo_ = st_ok ? st.out + (uint32_t)P.L + 3u : 0xFFFFFFFFu;
+        const uint32_t qo_ = st_ok ? st.out + qual_at : 0xFFFFFFFFu;
         uint32_t fix_mask = 0xFFu;
         if (tail_whole) {  // (wave-uniform) the read's last item: its eighth byte is the line break, then "+\n"
           const bool last = c + 1u == TI;
@@ -1776,11 +1795,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         uint32_t so[8];
         const uint32_t ib0 = __umul24(8u * c, bins);
 #pragma unroll
-        for (int h = 0; h < 8; h++) so[h] = __umul24(__umulhi(ib0 + (uint32_t)h * bins, st.inv), blk_bytes);
+        for (int h = 0; h < 8; h++) so[h] = __umul24(__umulhi(ib0 + (uint32_t)h * bins, st.inv), blk_bytes) + img_at;
         const uint32_t qo0 = so[0], qo1 = so[1];
         if (c == 0u) { so[0] += 128u * 4u; so[1] += 64u * 4u; }
         uint32_t sw[2], qw[2], acc;
-        sample8(img, code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
+        sample8(code4, lgW, cw, x, so, qo0, qo1, sw, qw, acc);
         const bool st_ok = st.ok && !(dg & 1u);
         const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
         const uint32_t qo_ = st_ok ? st.out + st.np + 3u : 0xFFFFFFFFu;
