@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage: tools/profile_round.sh <tag>   (on the GPU box, from the repo root)
 # The evidence of one kernel generation, written to gpurun_out/<tag>/ (copy it to profiles/<tag>/ afterwards):
-#   kernel_stats.csv    rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1` (C2 workload)
+#   kernel_stats.csv    rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5` (C2 workload)
 #   pmc_summary.json    per-kernel means of separate --pmc passes (FETCH_SIZE | WRITE_SIZE | two SQ groups + GRBM_GUI_ACTIVE)
 #   bench.json          the bench line of an unprofiled run of the same build
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
-B="python3 bench.py --steps 5 --warmup 1 --strong-scale 0 --no-cpu-baseline --no-host-pinned --no-md5"
+B="python3 bench.py --steps 20 --warmup 5 --strong-scale 0 --no-cpu-baseline --no-host-pinned --no-md5"   # (as many launches as the plain bench line times: the first few run at lower clocks)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > /dev/null 2> $out/trace.err || echo "trace failed"
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE"; do
