@@ -2256,9 +2256,10 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     const uint32_t inv_TI = (1u << 20) / TIf + 1u;
     // the list of the one-indel reads' clean items, where the table image leaves room for it (else those reads stay whole
     // in the general steps: same output)
-    const size_t clean_b = (size_t)EMIT_WAVES * CLEAN_CAP * 2;
-    const uint32_t clean_cap = getenv("SG_NO_CLEAN_STEPS") == nullptr && e.lds_fast + clean_b <= kLdsBytes ? CLEAN_CAP : 0u;
-    const size_t lds_fast = e.lds_fast + (clean_cap ? clean_b : 0);
+    // (CLEAN_CAP entries per wave, or as many 64s as fit beside a large image: the 41-symbol profiles leave 6.9 KB)
+    uint32_t clean_cap = (uint32_t)std::min<size_t>(CLEAN_CAP, ((kLdsBytes - e.lds_fast) / (EMIT_WAVES * 2)) & ~(size_t)63);
+    if (getenv("SG_NO_CLEAN_STEPS") != nullptr) clean_cap = 0;
+    const size_t lds_fast = e.lds_fast + (size_t)EMIT_WAVES * clean_cap * 2;
     auto launch_fast = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
       hipLaunchKernelGGL(kern, fgrid, dim3(EMIT_THREADS), lds_fast, s, P, B, TIf, inv_TI, clean_cap);
