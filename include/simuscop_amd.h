@@ -43,6 +43,10 @@ typedef struct sg_ctx sg_ctx;
  * 64-bit seed instead of clock-seeded mt19937 pairs (ThreadPool.cpp:41-49).                      */
 int sg_create(sg_ctx** ctx, int device, uint64_t seed);
 void sg_destroy(sg_ctx* ctx);
+/* Device blocks a destroyed context (or a grown buffer) gave up stay with the process and serve the next context's
+ * requests of their size (the reference keeps its `new[]` arenas per run likewise: nothing of it outlives main());
+ * this returns them to the runtime.  SG_BLOCK_CACHE_GB bounds what is kept (default 160, 0 = keep nothing).        */
+void sg_release_cached_memory(void);
 const char* sg_last_error(const sg_ctx* ctx); /* ctx may be NULL: error of a failed sg_create */
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
 int sg_set_stream(sg_ctx* ctx, void* hip_stream);

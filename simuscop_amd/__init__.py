@@ -28,6 +28,7 @@ ENGINE_SYMBOLS = [
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
     "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free", "sg_train_count",
+    "sg_release_cached_memory",
 ]
 
 
@@ -118,6 +119,8 @@ def load_engine():
     lib.sg_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint64]
     lib.sg_destroy.argtypes = [vp]
     lib.sg_destroy.restype = None
+    lib.sg_release_cached_memory.restype = None
+    lib.sg_release_cached_memory.argtypes = []
     lib.sg_last_error.argtypes = [vp]
     lib.sg_last_error.restype = C.c_char_p
     lib.sg_set_stream.argtypes = [vp, vp]
@@ -232,6 +235,11 @@ def run_config(config_path: str, **opts) -> SimuStats:
     if rc != 0:
         raise SimuError(f"simuReads failed (exit code {rc}): {err.value.decode(errors='replace')}")
     return st
+
+
+def release_cached_memory() -> None:
+    """Device blocks that finished contexts left with the process go back to the runtime (sg_release_cached_memory)."""
+    load_engine().sg_release_cached_memory()
 
 
 class Session:

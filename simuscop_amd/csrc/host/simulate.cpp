@@ -422,6 +422,9 @@ struct Driver {
       eng.check(sg_plan_range(eng.ctx, (uint32_t)a0, (uint32_t)a1), "sg_plan_range");
       st.t_plan_api += since(t_pl);
       st.t_sample += since(t0d);
+      if (getenv("SIMU_TRACE_PIECES") != nullptr)
+        fprintf(stderr, "[piece] %s %s segments %zu..%zu: upload %.4f s, sg_plan_range %.4f s\n", cur.popu.c_str(), cur.chr.c_str(), a0, a1,
+                since(t0d) - since(t_pl), since(t_pl));
       return;
     }
     const std::vector<Active>& act = cur.act;
@@ -485,9 +488,14 @@ struct Driver {
     auto t0 = Clock::now();
     uint64_t n1 = 0, n2 = 0, nf = 0;
     const int reps = opt.repeat_sample > 1 ? opt.repeat_sample : 1;
+    static const bool trace = getenv("SIMU_TRACE_PIECES") != nullptr;   // where a run's sampling time goes, piece by piece
     for (int r = 0; r < reps; r++) {
+      auto ts = Clock::now();
       eng.check(sg_sample(eng.ctx), "sg_sample");
+      const double d_sample = since(ts);
       eng.check(sg_result(eng.ctx, &n1, &n2, &nf), "sg_result");
+      if (trace) fprintf(stderr, "[piece] %s %s segments %zu..%zu: sg_sample %.4f s, with sg_result %.4f s, %llu fragments\n", cur.popu.c_str(),
+                         cur.chr.c_str(), c0, c1, d_sample, since(ts), (unsigned long long)nf);
       float ms[SG_K_COUNT];
       sg_kernel_times(eng.ctx, ms);
       for (int i = 0; i < SG_K_COUNT; i++) st.kernel_ms[i] += ms[i];

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -74,16 +75,96 @@ void launch_scan_u32(const uint32_t* in, uint32_t n, uint64_t* bsum, uint64_t* o
 
 namespace {
 
+// Device blocks released by a context stay with the process and serve the next request of their size on the same
+// device.  A whole-genome run allocates ~60 GB in a few dozen blocks and returns them at its end; the next run of the
+// process asked the runtime for the same blocks again, and every dozen runs or so ONE such hipMalloc took 2-5 s
+// (`SG_TRACE_ALLOC=1 python tools/c3_steps.py`: "hipMalloc 3455.3 MB: 4925.76 ms" in the thirteenth run, 20-40 ms in the
+// others) -- seventeen times the run itself.  Best fit within 1.5x; the cache holds at most SG_BLOCK_CACHE_GB (default
+// 160) and gives everything back through sg_release_cached_memory().  SG_BLOCK_CACHE_GB=0 turns it off.
+struct BlockCache {
+  struct Block { void* p; size_t cap; int dev; };
+  std::mutex mu;
+  std::vector<Block> blocks;   // oldest first
+  size_t held = 0;
+  static size_t limit() {
+    static const size_t v = [] {
+      const char* e = getenv("SG_BLOCK_CACHE_GB");
+      return (size_t)((e ? atof(e) : 160.0) * 1073741824.0);
+    }();
+    return v;
+  }
+  void* take(size_t want, int dev, size_t* cap) {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t best = blocks.size();
+    for (size_t i = 0; i < blocks.size(); i++)
+      if (blocks[i].dev == dev && blocks[i].cap >= want && blocks[i].cap <= want + want / 2 + (64u << 20) &&
+          (best == blocks.size() || blocks[i].cap < blocks[best].cap))
+        best = i;
+    if (best == blocks.size()) return nullptr;
+    void* p = blocks[best].p;
+    *cap = blocks[best].cap;
+    held -= blocks[best].cap;
+    blocks.erase(blocks.begin() + (long)best);
+    return p;
+  }
+  void give(void* p, size_t cap, int dev) {
+    if (cap > limit()) { (void)hipFree(p); return; }
+    // whoever gets the block next may write it at once: nothing of this process may still be using it (hipFree waits
+    // likewise)
+    int cur = dev;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur != dev) (void)hipSetDevice(cur);
+    std::vector<Block> drop;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      blocks.push_back({p, cap, dev});
+      held += cap;
+      while (held > limit() && !blocks.empty()) {
+        drop.push_back(blocks.front());
+        held -= blocks.front().cap;
+        blocks.erase(blocks.begin());
+      }
+    }
+    for (const Block& b : drop) (void)hipFree(b.p);
+  }
+  bool any() {
+    std::lock_guard<std::mutex> lk(mu);
+    return !blocks.empty();
+  }
+  void trim() {
+    std::vector<Block> drop;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      drop.swap(blocks);
+      held = 0;
+    }
+    for (const Block& b : drop) (void)hipFree(b.p);
+  }
+};
+BlockCache& block_cache() {
+  static BlockCache* c = new BlockCache;  // (never destroyed: contexts may outlive static destructors)
+  return *c;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int dev = 0;
   int ensure(size_t bytes) {
     if (bytes <= cap) return 0;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    release();
     size_t want = bytes + bytes / 8 + 256;
     static const bool trace = getenv("SG_TRACE_ALLOC") != nullptr;
+    (void)hipGetDevice(&dev);
+    if ((p = block_cache().take(want, dev, &cap)) != nullptr) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && block_cache().any()) {  // the cache may be what is in the way
+      block_cache().trim();
+      e = hipMalloc(&p, want);
+    }
     if (trace)
       fprintf(stderr, "[sg] hipMalloc %.1f MB: %.2f ms\n", want / 1048576.0,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -91,7 +172,10 @@ struct DevBuf {
     cap = want;
     return 0;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() {
+    if (p) block_cache().give(p, cap, dev);
+    p = nullptr; cap = 0;
+  }
   template <class T> T* as() const { return (T*)p; }
 };
 
@@ -1405,6 +1489,8 @@ int sg_host_alloc(sg_ctx* ctx, uint64_t bytes, void** host_ptr) {
   SG_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
   return SG_OK;
 }
+
+void sg_release_cached_memory(void) { block_cache().trim(); }
 
 int sg_host_free(sg_ctx* ctx, void* host_ptr) {
   if (!ctx) return SG_ERR_INVALID;

@@ -240,3 +240,25 @@ def test_a_pass_larger_than_the_buffers_it_was_launched_into(tmp_path, monkeypat
     waited = texts_of(order)
     assert queued == waited
     assert queued[1][0] > 4 * queued[0][0] and queued[3][0] > 4 * queued[2][0]
+
+
+def test_runs_in_one_process_reuse_device_blocks(tmp_path):
+    """The device blocks a finished run gave up serve the next run of the process (sg_api.cpp BlockCache; what keeps a
+    sequence of whole-genome runs off the allocator, see tools/c3_steps.py).  They come back dirty -- holding the other
+    run's tables, rows and text -- so: the same configuration before and after a different one, and after the cache was
+    emptied, must write the same bytes; so must a run with the cache turned off in a fresh process (the parity tests)."""
+    cfg_a = cases.build_case("indel_rich_n_islands_pe", str(tmp_path / "a"))
+    cfg_b = cases.build_case("wes_tight_targets_pe", str(tmp_path / "b"))
+
+    def run(cfg, tag):
+        out = str(tmp_path / tag)
+        simuscop_amd.run_config(cfg, device=0, quiet=1, write_files=1, seed=77, output_dir=out)
+        return {f: hashlib.md5(open(os.path.join(out, f), "rb").read()).hexdigest() for f in sorted(os.listdir(out))}
+
+    first_a, first_b = run(cfg_a, "a1"), run(cfg_b, "b1")
+    assert first_a and first_b and first_a != first_b
+    assert run(cfg_a, "a2") == first_a           # into blocks that held b's data
+    assert run(cfg_b, "b2") == first_b
+    simuscop_amd.release_cached_memory()
+    assert run(cfg_a, "a3") == first_a           # into fresh blocks
+    simuscop_amd.release_cached_memory()
