@@ -1502,7 +1502,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // 8c - 5 .. 8c + 7
     uint32_t kb = 0, ca0 = 0, n_whole = 0, ka = 0, n_gen = 0, vscan = 0;
     bool split_l = false;
-    if (clean_cap) {
+    // (only where a group has enough one-indel reads for about two clean steps: with fewer the split cannot pay, see below,
+    // and the other profiles' groups -- a third to a twentieth of XTen's one-indel reads -- skip its bookkeeping)
+    const bool cand0_l = act_l && nev_l == 1u && !((my1.x >> 30) & 1u);
+    if (clean_cap != 0u && (uint32_t)__popcll(__ballot(cand0_l)) * (TI - 2u) >= 96u) {
       const uint32_t ew = my1.w;
       const uint32_t ej = ew & 0xFFFFu, elen = (ew >> 16) & 0x7FFFu;
       const bool del = (ew >> 31) != 0u;
@@ -1512,7 +1515,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       ca0 = (fs + 12u) >> 3;                      // items ca0 .. n_whole-1: wholly after (8c - 5 >= fs)
       ka = n_whole > ca0 ? n_whole - ca0 : 0u;
       n_gen = ka ? (ca0 - kb) + (items - n_whole) : items - kb;   // what is left for the general steps
-      const bool cand_l = act_l && nev_l == 1u && !((my1.x >> 30) & 1u) && items <= 255u && kb + ka != 0u;
+      const bool cand_l = cand0_l && items <= 255u && kb + ka != 0u;
       // as many of them, in lane order, as the two lists hold (behind the other single items, counted below)
       uint32_t v = cand_l ? ((kb + ka) << 16) | n_gen : 0u;
 #pragma unroll
@@ -1526,6 +1529,22 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
                               (uint32_t)__popcll(__ballot(extra_l == 1u || extra_l == 2u)) + (uint32_t)__popcll(__ballot(extra_l == 2u));
       split_l = cand_l && (v >> 16) <= clean_cap && others + (v & 0xFFFFu) <= OVF_CAP;
       // (a prefix in lane order: the sums only grow)
+      // Does the split pay in this group?  Steps are whole: a few clean items make a clean step of their own, and what
+      // they leave behind may still need as many general steps as before (the 125-base profile: one read in ten has one
+      // indel, and every plain read sends its partial last item through the general steps anyway -- with the split
+      // unconditional its launch ran 3.6 % MORE instructions).  Step counts either way from the sums at hand, priced at
+      // the loops' measured instructions per step (general 390-590 by profile: 480, clean 260, composing the lists ~250).
+      const unsigned long long ms = __ballot(split_l);
+      if (ms) {
+        const uint32_t tot_s = (uint32_t)__shfl((int)v, 63 - __builtin_clzll(ms), 64);
+        const uint32_t n_cl = tot_s >> 16, n_gn = tot_s & 0xFFFFu;
+        const uint32_t whole = (uint32_t)__popcll(__ballot(act_l && !plain_l && !split_l));   // reads that stay whole in the general steps
+        const uint32_t s0 = (whole + (uint32_t)__popcll(ms)) * TI + others, s1 = whole * TI + others + n_gn;
+        const uint32_t rem = n_cl & 63u, mv = (rem != 0u && rem <= ((0u - s1) & 63u)) ? rem : 0u;   // (the partial clean step that moves, below)
+        const uint32_t before = 48u * ((s0 + 63u) >> 6);
+        const uint32_t after = 26u * ((n_cl - mv + 63u) >> 6) + 48u * ((s1 + mv + 63u) >> 6) + 25u;
+        if (after >= before) split_l = false;
+      }
       kb = split_l ? kb : 0u;
       ka = split_l ? ka : 0u;
       n_gen = split_l ? n_gen : 0u;
