@@ -1238,12 +1238,26 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
   return slow;
 }
 
-// n (< 16) bytes of the 128-bit value (lo, hi) to q: 8/4/2/1-byte pieces
+// n (< 16) bytes of the 128-bit value (lo, hi) to q, as TWO overlapping pieces of the largest power of two <= n: its
+// first bytes and its last.  (Lane = record here: every store instruction touches 64 different lines, so the number of
+// pieces is what these stores cost; 8/4/2/1-byte pieces made three or four of a 15-byte name.)
 __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, uint32_t n) {
-  if (n & 8u) { __builtin_memcpy(q, &lo, 8); q += 8; lo = hi; }
-  if (n & 4u) { const uint32_t v = (uint32_t)lo; __builtin_memcpy(q, &v, 4); q += 4; lo >>= 32; }
-  if (n & 2u) { const uint16_t v = (uint16_t)lo; __builtin_memcpy(q, &v, 2); q += 2; lo >>= 16; }
-  if (n & 1u) *q = (uint8_t)lo;
+  if (n >= 8u) {
+    __builtin_memcpy(q, &lo, 8);
+    const uint32_t k = 8u * (n - 8u);   // bit offset of the last eight bytes (0 .. 56)
+    const uint64_t v = k ? (lo >> k) | (hi << (64u - k)) : lo;
+    __builtin_memcpy(q + n - 8u, &v, 8);
+  } else if (n >= 4u) {
+    const uint32_t a = (uint32_t)lo, b = (uint32_t)(lo >> (8u * (n - 4u)));
+    __builtin_memcpy(q, &a, 4);
+    __builtin_memcpy(q + n - 4u, &b, 4);
+  } else if (n >= 2u) {
+    const uint16_t a = (uint16_t)lo, b = (uint16_t)(lo >> (8u * (n - 2u)));
+    __builtin_memcpy(q, &a, 2);
+    __builtin_memcpy(q + n - 2u, &b, 2);
+  } else if (n == 1u) {
+    *q = (uint8_t)lo;
+  }
 }
 
 #define SLOW_CAP 128  // per-wave queue of items deferred to the generic code

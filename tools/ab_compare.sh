@@ -1,6 +1,6 @@
 # A/B timing of engine builds on one box: every directory given holds a built copy of the repo ('.' = this one)
 dirs="${@:-_ab .}"
-for r in 1 2; do
+for r in $(seq 1 ${AB_ROUNDS:-2}); do
 for d in $dirs; do
   for p in ${AB_PROFILES:-xten}; do
     (cd $d && python3 bench.py --steps 20 --warmup 3 --strong-scale 0 --profile $p --no-cpu-baseline --no-host-pinned --no-md5 2>/dev/null | python3 -c "
