@@ -453,19 +453,37 @@ void Fasta::open_owned_on_device(const std::string& ref_file, sg_ctx* ctx, int t
   }
   void* stage[2] = {nullptr, nullptr};
   try {
+    const bool trace = getenv("SIMU_TRACE_LOAD") != nullptr;   // phase times of the ingest on stderr
+    using Clk = std::chrono::steady_clock;
+    auto secs = [](Clk::time_point a) { return std::chrono::duration<double>(Clk::now() - a).count(); };
+    auto t_ph = Clk::now();
     eng_check(ctx, sg_reference_begin(ctx, total), "sg_reference_begin");
+    const double t_begin = secs(t_ph);
+    t_ph = Clk::now();
     const uint64_t kChunk = 64u << 20;
     for (int i = 0; i < 2 && total; i++) eng_check(ctx, sg_host_alloc(ctx, std::min<uint64_t>(kChunk, total), &stage[i]), "sg_host_alloc");
+    const double t_pin = secs(t_ph);
+    double t_read = 0, t_wait = 0;
+    t_ph = Clk::now();
     int cur = 0;
     for (const Piece& pc : pieces)
       for (uint64_t off = 0; off < pc.bytes; off += kChunk, cur ^= 1) {
         const uint64_t n = std::min<uint64_t>(kChunk, pc.bytes - off);
+        auto t1 = Clk::now();
         parallel_pread(fd, (uint8_t*)stage[cur], pc.file_off + off, n, threads);  // overlaps the copy of the other buffer
+        t_read += secs(t1);
+        t1 = Clk::now();
         eng_check(ctx, sg_sync(ctx), "sg_sync");
+        t_wait += secs(t1);
         eng_check(ctx, sg_reference_chunk(ctx, pc.dev_off + off, stage[cur], n), "sg_reference_chunk");
       }
     eng_check(ctx, sg_sync(ctx), "sg_sync");
+    const double t_stream = secs(t_ph);
+    t_ph = Clk::now();
     eng_check(ctx, sg_reference_commit(ctx, tab.data(), (uint32_t)tab.size()), "sg_reference_commit");
+    if (trace)
+      fprintf(stderr, "load trace: device buffer %.3fs, pinned staging %.3fs, stream %.3fs (pread %.3fs, waiting for copies %.3fs) of %.2f GB, commit %.3fs\n",
+              t_begin, t_pin, t_stream, t_read, t_wait, total / 1e9, secs(t_ph));
   } catch (...) {
     ::close(fd);
     for (void* b : stage) if (b) sg_host_free(ctx, b);

@@ -2292,6 +2292,7 @@ void launch_emit(const DevProfile& P, const DevBatch& B, hipStream_t s, bool for
     // (CLEAN_CAP entries per wave, or as many 64s as fit beside a large image: the 41-symbol profiles leave 6.9 KB)
     uint32_t clean_cap = (uint32_t)std::min<size_t>(CLEAN_CAP, ((kLdsBytes - e.lds_fast) / (EMIT_WAVES * 2)) & ~(size_t)63);
     if (getenv("SG_NO_CLEAN_STEPS") != nullptr) clean_cap = 0;
+    if (const char* e = getenv("SG_CLEAN_CAP")) clean_cap = std::min(clean_cap, (uint32_t)strtoul(e, nullptr, 10) & ~63u);  // (tests: a list that overflows)
     const size_t lds_fast = e.lds_fast + (size_t)EMIT_WAVES * clean_cap * 2;
     auto launch_fast = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);

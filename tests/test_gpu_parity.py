@@ -64,13 +64,14 @@ def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
     batches are cut into many memory-bounded pieces (SIMU_PIECE_SLOTS), and a run that plans its windows on the host
     (SIMU_HOST_PLAN; the default makes the window table on the device: sg_windows_build / sg_plan_windows), and a run
     whose one-indel reads stay whole in the general steps (SG_NO_CLEAN_STEPS: what profiles with a table image too large
-    for the clean-item list get)."""
+    for the clean-item list get) or only some of them fit the list (SG_CLEAN_CAP=64: the first in lane order are split,
+    the others stay whole)."""
     cfg = cases.build_case(name, str(tmp_path))
     outs = {}
     for tag, extra_env in (("queue", {}), ("overflow", {"SG_SLOWQ_CAP": "3"}), ("generic", {"SG_DIAG": "0"}),
                            ("pieces", {"SIMU_PIECE_SLOTS": "1500"}), ("host_plan", {"SIMU_HOST_PLAN": "1"}),
                            ("host_plan_pieces", {"SIMU_HOST_PLAN": "1", "SIMU_PIECE_SLOTS": "1500"}),
-                           ("no_clean_steps", {"SG_NO_CLEAN_STEPS": "1"})):
+                           ("no_clean_steps", {"SG_NO_CLEAN_STEPS": "1"}), ("small_clean_list", {"SG_CLEAN_CAP": "64"})):
         d = str(tmp_path / tag)
         err = _run_gpu(cfg, d, env=dict(os.environ, **extra_env))
         outs[tag] = {f: open(os.path.join(d, f), "rb").read() for f in _files(d)}
@@ -80,7 +81,7 @@ def test_generic_item_queue_and_its_overflow_path(name, tmp_path):
             assert _stat(err, "requeued_batches") > 0, err
         if tag == "generic":
             assert _stat(err, "queued_items") == 0, err
-    assert outs["queue"] == outs["overflow"] == outs["generic"] == outs["pieces"] == outs["host_plan"] == outs["host_plan_pieces"] == outs["no_clean_steps"] and outs["queue"]
+    assert outs["queue"] == outs["overflow"] == outs["generic"] == outs["pieces"] == outs["host_plan"] == outs["host_plan_pieces"] == outs["no_clean_steps"] == outs["small_clean_list"] and outs["queue"]
 
 
 def _records(blob):
