@@ -442,10 +442,12 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
   uint32_t* len_tok = code + 288;
   uint32_t* dist_code = len_tok + kGzLenTokens;
   uint32_t* wave_tot = dist_code + 32;                      // [8]
+  uint8_t* cl8 = (uint8_t*)(wave_tot + 8);                  // [256] code length of every literal
   __shared__ uint32_t next_c;
   for (uint32_t i = threadIdx.x; i < 288u; i += kGzThreads) code[i] = D.code[i];
   for (uint32_t i = threadIdx.x; i < kGzLenTokens; i += kGzThreads) len_tok[i] = D.len_tok[i];
   for (uint32_t i = threadIdx.x; i < 32u; i += kGzThreads) dist_code[i] = D.dist_code[i];
+  for (uint32_t i = threadIdx.x; i < 256u; i += kGzThreads) cl8[i] = (uint8_t)(D.code[i] >> 16);
   __syncthreads();
   for (uint32_t c = blockIdx.x; c < D.n_chunks;) {
     const uint64_t left = D.bytes - (uint64_t)c * kGzChunk;
@@ -469,23 +471,50 @@ __global__ __launch_bounds__(kGzThreads, 4) void gz_match_kernel(DevDeflate D) {
         jumps |= (uint64_t)((len_tok[len] >> 24) + (dist_code[ds] >> 16) + eb) << (8u * j);
       }
     }
-    // one pass over the lane's bytes: code lengths of the literals; the bit offset at which each match starts (ten bits
-    // each, shifted in from the top: the first match ends up lowest)
-    uint32_t bits = 0;
-    uint64_t offs = 0;
+    // Code lengths of the lane's literals and the bit offset at which each match starts.  (Until round 3 one pass over the
+    // 64 bytes carrying both along: ~1,500 of the kernel's ~4,400 instructions per lane.)  Now by words: the four code
+    // lengths of a word from a byte table, packed; covered and non-data bytes masked out; v_sad_u8 sums a word's four
+    // bytes, accumulating, which gives the literal bits up to every word boundary; a match start needs the sum up to its
+    // word and the bytes of its word below it -- indexed by a lane-variable word number, so the packed lengths and the
+    // prefix sums go through a private LDS record (25 words per lane: an odd stride, no bank conflicts; the text and the
+    // hash table are dead by now, gz_merge's scratch words excepted).
+    uint32_t* rec_lds = tab + 2u * kGzThreads + threadIdx.x * 25u;
+    uint64_t lit = ~L.cover;                                               // bit k: byte k is a literal
+    lit = L.first >= 64u ? 0ull : lit & ~((1ull << L.first) - 1ull);
+    uint32_t run_sum = 0, prev_sum = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kGzLaneBytes; k++) {
-      const bool st = (L.starts >> k) & 1ull;
-      offs = st ? (offs >> 10) | ((uint64_t)bits << 50) : offs;
-      bits += st ? (uint32_t)jumps & 0xFFu : 0u;
-      jumps = st ? jumps >> 8 : jumps;
-      const uint32_t cl = code[(L.w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu] >> 16;
-      bits += (k >= L.first && !((L.cover >> k) & 1ull)) ? cl : 0u;
+    for (uint32_t i = 0; i < 16u; i++) {
+      const uint32_t wv_ = L.w[i];
+      const uint32_t packed = (uint32_t)cl8[wv_ & 0xFFu] | ((uint32_t)cl8[(wv_ >> 8) & 0xFFu] << 8) | ((uint32_t)cl8[(wv_ >> 16) & 0xFFu] << 16) |
+                              ((uint32_t)cl8[wv_ >> 24] << 24);
+      const uint32_t m4 = (uint32_t)(lit >> (4u * i)) & 0xFu;
+      const uint32_t keep = ((m4 * 0x00204081u) & 0x01010101u) * 0xFFu;    // four mask bits -> four mask bytes
+      const uint32_t cw_ = packed & keep;
+      rec_lds[i] = cw_;
+      run_sum = __builtin_amdgcn_sad_u8(cw_, 0u, run_sum);                 // + the word's four bytes
+      if (i & 1u) rec_lds[16u + (i >> 1)] = (prev_sum & 0xFFFFu) | (run_sum << 16);   // inclusive prefix of words i-1, i
+      else prev_sum = run_sum;
     }
-    offs = nm ? offs >> (10u * (kGzLaneMatches - nm)) : 0ull;
+    uint32_t bits = 0;   // token bits of the matches before the current one
     uint32_t mw[kGzLaneMatches];
+    {
+      uint64_t st = L.starts;
 #pragma unroll
-    for (uint32_t j = 0; j < kGzLaneMatches; j++) mw[j] = L.mw[j] | ((uint32_t)((offs >> (10u * j)) & 0x3FFu) << 21);
+      for (uint32_t j = 0; j < kGzLaneMatches; j++) {
+        uint32_t off = 0;
+        if (st != 0ull) {
+          const uint32_t s0 = (uint32_t)__builtin_ctzll(st);
+          st &= st - 1ull;
+          const uint32_t wj = s0 >> 2, bj = s0 & 3u;
+          const uint32_t below = rec_lds[wj] & ((1u << (8u * bj)) - 1u);
+          const uint32_t pw = wj ? ((const uint16_t*)(rec_lds + 16))[wj - 1u] : 0u;
+          off = pw + __builtin_amdgcn_sad_u8(below, 0u, 0u) + bits;
+          bits += (uint32_t)(jumps >> (8u * j)) & 0xFFu;
+        }
+        mw[j] = L.mw[j] | ((off & 0x3FFu) << 21);
+      }
+    }
+    bits += run_sum;
     // record: the start mask and six words (length - 3 | distance - 1 << 6 | bit offset in the lane << 21 | 1 << 31)
     uint4* rec = D.rec + ((size_t)c * kGzThreads + threadIdx.x) * 2;
     rec[0] = make_uint4((uint32_t)L.starts, (uint32_t)(L.starts >> 32), mw[0], mw[1]);
@@ -641,7 +670,7 @@ __global__ __launch_bounds__(kGzThreads) void gz_encode_kernel(DevDeflate D, uin
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
-static size_t gz_token_lds() { return ((size_t)kGzTab + 4 + 288 + kGzLenTokens + 32 + 8 + 64) * 4 + kGzChunk + kGzTxtPad; }
+static size_t gz_token_lds() { return ((size_t)kGzTab + 4 + 288 + kGzLenTokens + 32 + 8 + 64 + 64) * 4 + kGzChunk + kGzTxtPad; }
 void launch_gz_hist(const void* d, uint32_t n_chunks, hipStream_t s) {
   if (!n_chunks) return;
   const size_t lds = gz_token_lds();
