@@ -994,7 +994,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(DevProfile P, DevBat
 //     the "tails" Philox call only for a head on a threshold);
 //   * table addresses come from a per-item look-up row (bin offsets of the item's eight positions; the short
 //     contexts of a read's first two bases are table regions of their own, selected by that row);
-//   * a group's reads walk the steps as one item stream, 64 items per step, ordered by event class;
+//   * a group's reads walk three loops of steps, 64 items per step: the plain reads (no indel, the profile's own length)
+//     their own stream, the items of one-indel reads that lie wholly before or behind the indel a list of their own
+//     (the plain step with computed bins and a shifted template), everything else one general stream ordered by
+//     event class;
 //   * what is per read rather than per item: the name goes out at phase 0 (lane = read; prefix from the kernel
 //     arguments, the read's own part from its row), the partial last item, "\n+\n" and '\n' are stored by a per-read
 //     pass once per group (the last item waits in the read's own LDS row);
@@ -1023,15 +1026,7 @@ __device__ __noinline__ uint32_t tail_word(uint32_t slot, uint32_t c, uint32_t h
   return l == 0u ? y[0] : l == 1u ? y[1] : l == 2u ? y[2] : y[3];
 }
 
-// The 8-base block of the straight-line kernels: eight positions' substitution and quality decisions from their heads
-// words.  Every VALU instruction costs about the same here (~4.2 cycles in this mix), so the block is written for few
-// instructions: 16-bit fields that operand selects (SDWA) pick for free, byte permutes for packing.
-//   cw   13 source codes, 2 bits each (output positions i0-5 .. i0+7)      x[h]  heads word of position i0 + h
-//   so[h] byte offset of position h's bin in the table image (+ the short-context region of a read's first two bases),
-//   qo0/qo1 the plain bin offsets of positions 0 and 1
-// Out: sw = the eight called characters (= the reference bases), qw = the eight quality characters, acc bit 17 + h = the
-// head could not decide base h (possible substitution, or a head equal to a threshold's): the fix-up pass redoes it.
-// one base of the block (see sample8)
+// one base of the 8-base block (sample8 below)
 template <int H>
 __device__ __forceinline__ void sample1(uint32_t col_sh, uint32_t col_mask, uint32_t cw, uint32_t wh, uint32_t so_h, uint32_t qo_h, uint32_t cd4_w,
                                         uint32_t& acc, uint32_t& sy) {
@@ -1058,6 +1053,15 @@ __device__ __forceinline__ void sample1(uint32_t col_sh, uint32_t col_mask, uint
   sy = __builtin_amdgcn_bitop3_b32(e >> 8, e, d_q, BITOP_XOR_AND);
 }
 
+// The 8-base block of the straight-line kernels: eight positions' substitution and quality decisions from their heads
+// words.  Written for few instructions and, where there is a choice, for the ones that issue at the full rate (add, sub,
+// and/or/xor, right shifts: 2.3 cycles against 4.2, tools/valu_microbench.hip): 16-bit fields that operand selects (SDWA)
+// pick for free, byte permutes for packing, shift + mask instead of bit-field extract + left shift.
+//   cw   13 source codes, 2 bits each (output positions i0-5 .. i0+7)      x[h]  heads word of position i0 + h
+//   so[h] LDS byte address of position h's bin in the table image (+ the short-context region of a read's first two bases),
+//   qo0/qo1 the plain bin addresses of positions 0 and 1
+// Out: sw = the eight called characters (= the reference bases), qw = the eight quality characters, acc bit 17 + h = the
+// head could not decide base h (possible substitution, or a head equal to a threshold's): the fix-up pass redoes it.
 __device__ __forceinline__ void sample8(const uint32_t* code4, uint32_t lgW, uint32_t cw, const uint32_t (&x)[8],
                                         const uint32_t (&so)[8], uint32_t qo0, uint32_t qo1, uint32_t (&sw)[2], uint32_t (&qw)[2],
                                         uint32_t& acc_out) {
