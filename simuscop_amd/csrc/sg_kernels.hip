@@ -1243,22 +1243,24 @@ __device__ __forceinline__ bool fast_item(const DevProfile& P, const DevBatch& B
 }
 
 // n (< 16) bytes of the 128-bit value (lo, hi) to q, as TWO overlapping pieces of the largest power of two <= n: its
-// first bytes and its last.  (Lane = record here: every store instruction touches 64 different lines, so the number of
+// first bytes and its last (one piece when n is that power).  (Lane = record here: every store instruction touches 64 different lines, so the number of
 // pieces is what these stores cost; 8/4/2/1-byte pieces made three or four of a 15-byte name.)
 __device__ __forceinline__ void store_var(uint8_t* q, uint64_t lo, uint64_t hi, uint32_t n) {
   if (n >= 8u) {
     __builtin_memcpy(q, &lo, 8);
-    const uint32_t k = 8u * (n - 8u);   // bit offset of the last eight bytes (0 .. 56)
-    const uint64_t v = k ? (lo >> k) | (hi << (64u - k)) : lo;
-    __builtin_memcpy(q + n - 8u, &v, 8);
+    if (n > 8u) {
+      const uint32_t k = 8u * (n - 8u);   // bit offset of the last eight bytes (8 .. 56)
+      const uint64_t v = (lo >> k) | (hi << (64u - k));
+      __builtin_memcpy(q + n - 8u, &v, 8);
+    }
   } else if (n >= 4u) {
     const uint32_t a = (uint32_t)lo, b = (uint32_t)(lo >> (8u * (n - 4u)));
     __builtin_memcpy(q, &a, 4);
-    __builtin_memcpy(q + n - 4u, &b, 4);
+    if (n > 4u) __builtin_memcpy(q + n - 4u, &b, 4);
   } else if (n >= 2u) {
     const uint16_t a = (uint16_t)lo, b = (uint16_t)(lo >> (8u * (n - 2u)));
     __builtin_memcpy(q, &a, 2);
-    __builtin_memcpy(q + n - 2u, &b, 2);
+    if (n > 2u) __builtin_memcpy(q + n - 2u, &b, 2);
   } else if (n == 1u) {
     *q = (uint8_t)lo;
   }
@@ -1363,12 +1365,41 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
             write_name(rec, B.prefix, B.prefix_len, my0.z, my0.w, PAIRED ? 1u : 0u, m);
           } else {
             const uint64_t p_lo = ((uint64_t)B.prefix_w[1] << 32) | B.prefix_w[0], p_hi = ((uint64_t)B.prefix_w[3] << 32) | B.prefix_w[2];
-            if (B.prefix_len == 16u) { __builtin_memcpy(rec, &p_lo, 8); __builtin_memcpy(rec + 8, &p_hi, 8); }
-            else store_var(rec, p_lo, p_hi, B.prefix_len);
             const uint4 tx = B.meta[idx * 3 + 2];
-            uint8_t* q = rec + B.prefix_len;
-            if (nv == 16u) __builtin_memcpy(q, &tx, 16);
-            else store_var(q, ((uint64_t)tx.y << 32) | tx.x, ((uint64_t)tx.w << 32) | tx.z, nv);
+            const uint64_t b0 = ((uint64_t)tx.y << 32) | tx.x, b1 = ((uint64_t)tx.w << 32) | tx.z;
+            const uint32_t plen = B.prefix_len, hb = plen + nv;   // the name's bytes: prefix, then the read's own text
+            if (plen < 16u && hb >= 16u && hb <= 24u) {
+              // the usual case ("@sim#20#" + "592246#30000/1\n"): the name as ONE string (both parts are zero beyond their
+              // ends), its first sixteen bytes and its last eight -- two stores where prefix + two text pieces were three
+              // (lane = record: every store instruction touches 64 lines, and on the 75-base profiles the names and tails
+              // are a quarter of the kernel's time)
+              const uint32_t sh = 8u * plen;
+              uint64_t w0, w1, w2;
+              if (sh < 64u) {
+                w0 = p_lo | (b0 << sh);
+                w1 = p_hi | (b1 << sh) | (sh ? b0 >> (64u - sh) : 0ull);
+                w2 = sh ? b1 >> (64u - sh) : 0ull;
+              } else {
+                const uint32_t t2 = sh - 64u;
+                w0 = p_lo;
+                w1 = p_hi | (b0 << t2);
+                w2 = (b1 << t2) | (t2 ? b0 >> (64u - t2) : 0ull);
+              }
+              struct { uint64_t a, b; } first = {w0, w1};
+              __builtin_memcpy(rec, &first, 16);
+              const uint32_t n2 = hb - 16u;
+              if (n2) {
+                const uint32_t k = 8u * n2;
+                const uint64_t v = k == 64u ? w2 : (w1 >> k) | (w2 << (64u - k));
+                __builtin_memcpy(rec + hb - 8u, &v, 8);
+              }
+            } else {
+              if (plen == 16u) { __builtin_memcpy(rec, &p_lo, 8); __builtin_memcpy(rec + 8, &p_hi, 8); }
+              else store_var(rec, p_lo, p_hi, plen);
+              uint8_t* q = rec + plen;
+              if (nv == 16u) __builtin_memcpy(q, &tx, 16);
+              else store_var(q, b0, b1, nv);
+            }
           }
         }
       }
