@@ -39,6 +39,18 @@ using std::vector;
 
 static const double ZERO_FINAL = 2.2204e-16;  // lib/mydefine/MyDefine.cpp:20
 
+// (long) of a double the way the reference's machine code does it (cvttsd2si): a NaN or a value out of range gives
+// LONG_MIN.  The reference divides by weighted lengths that can be zero (Genome.cpp:803-817: a chromosome, or a whole
+// population, whose every window holds an N or lies outside the targets) and casts the NaN; what follows -- sums that wrap,
+// negative read counts that sample nothing -- is what its binary does, and what a user of such inputs sees: no reads from
+// that chromosome, the run goes on.  Restated as such instead of refused.
+static inline long to_long_x86(double v) {
+  if (!(v > -9223372036854775808.0 && v < 9223372036854775808.0)) return (long)0x8000000000000000ull;
+  return (long)v;
+}
+static inline long wrap_add(long a, long b) { return (long)((unsigned long)a + (unsigned long)b); }
+static inline long wrap_sub(long a, long b) { return (long)((unsigned long)a - (unsigned long)b); }
+
 struct Fail : std::runtime_error {
   explicit Fail(const string& m) : std::runtime_error(m) {}
 };
@@ -1460,11 +1472,11 @@ struct Genome {
     long sum = 0;
     g.fragRCs.clear();
     for (size_t i = 0; i < g.fragWeights.size(); i++) {
-      long rcv = (long)(g.fragWeights[i] * readCount / totalWL);
+      long rcv = to_long_x86(g.fragWeights[i] * readCount / totalWL);
       g.fragRCs.push_back((int)rcv);
-      sum += rcv;
+      sum = wrap_add(sum, rcv);
     }
-    if (sum < readCount) g.fragRCs[0] += (int)(readCount - sum);
+    if (sum < readCount) g.fragRCs[0] += (int)wrap_sub(readCount, sum);
     g.readCount = readCount;
   }
 
@@ -1494,21 +1506,20 @@ struct Genome {
       const string& chr = chromosomes[i];
       vector<Segment>& cs = segsOfPopu[chr];
       double chrWL = chrWLens[chr];
-      if (i < chromosomes.size() - 1) chrReads = (long)(reads * (chrWL / WL));
-      else chrReads = reads - curReads;
+      if (i < chromosomes.size() - 1) chrReads = to_long_x86(reads * (chrWL / WL));
+      else chrReads = wrap_sub(reads, curReads);
       long sum = 0;
       for (size_t j = 0; j < cs.size(); j++) {
         if (j < cs.size() - 1) {
-          double share = getWeightedLength(cs[j], (uint32_t)j) / chrWL;
-          if (std::isnan(share)) throw Fail("chromosome " + chr + " has zero weighted length (0/0 in Genome::setReadCounts)");
-          long segReadCount = (long)(share * chrReads);
+          double share = getWeightedLength(cs[j], (uint32_t)j) / chrWL;   // 0/0 for a chromosome without weight: see to_long_x86
+          long segReadCount = to_long_x86(share * chrReads);
           segSetReadCount(cs[j], (uint32_t)j, segReadCount);
-          sum += segReadCount;
+          sum = wrap_add(sum, segReadCount);
         } else {
-          segSetReadCount(cs[j], (uint32_t)j, chrReads - sum);
+          segSetReadCount(cs[j], (uint32_t)j, wrap_sub(chrReads, sum));
         }
       }
-      curReads += chrReads;
+      curReads = wrap_add(curReads, chrReads);
     }
   }
 

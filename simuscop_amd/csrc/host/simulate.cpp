@@ -27,6 +27,15 @@
 #include "genome.h"
 
 namespace simu {
+
+// (long) of a double as the reference's machine code does it (cvttsd2si: NaN or out of range -> LONG_MIN), and sums that
+// wrap like its 64-bit registers: see set_read_counts
+static inline long to_long_x86(double v) {
+  if (!(v > -9223372036854775808.0 && v < 9223372036854775808.0)) return (long)0x8000000000000000ull;
+  return (long)v;
+}
+static inline long wrap_add(long a, long b) { return (long)((unsigned long)a + (unsigned long)b); }
+static inline long wrap_sub(long a, long b) { return (long)((unsigned long)a - (unsigned long)b); }
 namespace {
 
 using Clock = std::chrono::steady_clock;
@@ -273,20 +282,23 @@ struct Driver {
     for (size_t i = 0; i < genome.chromosomes.size(); i++) {
       ChromPlan& plan = genome.plans[popu][genome.chromosomes[i]];
       const double cw = chr_wl[i];
-      const long chr_reads = i + 1 < genome.chromosomes.size() ? (long)(reads * (cw / WL)) : reads - cur;
+      // A chromosome -- or a whole population -- without weighted length (every window holds an N, or lies outside the
+      // targets) makes these divisions 0/0 in the reference too (Genome.cpp:803-817).  Its binary casts the NaN (cvttsd2si:
+      // LONG_MIN), the sums wrap, the read counts come out negative and sample nothing: no reads from that chromosome,
+      // the run goes on.  The same arithmetic here (the oracle restates it alike); counts <= 0 are skipped below.
+      const long chr_reads = i + 1 < genome.chromosomes.size() ? to_long_x86(reads * (cw / WL)) : wrap_sub(reads, cur);
       long sum = 0;
       for (size_t j = 0; genome.owns(genome.chromosomes[i]) && j < plan.segs.size(); j++) {
         Segment& g = plan.segs[j];
         if (j + 1 < plan.segs.size()) {
           const double share = seg_weight(plan, g) / cw;
-          if (std::isnan(share)) throw Error("ERROR: chromosome " + genome.chromosomes[i] + " has zero weighted length");
-          g.read_count = (long)(share * chr_reads);
-          sum += g.read_count;
+          g.read_count = to_long_x86(share * chr_reads);
+          sum = wrap_add(sum, g.read_count);
         } else {
-          g.read_count = chr_reads - sum;
+          g.read_count = wrap_sub(chr_reads, sum);
         }
       }
-      cur += chr_reads;
+      cur = wrap_add(cur, chr_reads);
     }
     st.t_plan += since(t0);
   }
@@ -331,7 +343,7 @@ struct Driver {
       std::vector<sg_active_seg> active;
       for (size_t k = 0; k < plan.segs.size(); k++) {
         const Segment& g = plan.segs[k];
-        if (!g.has_seq || g.read_count == 0) continue;
+        if (!g.has_seq || g.read_count <= 0) continue;   // (negative: what a weightless chromosome's NaN shares turn into)
         uint64_t w = plan.seg_win0[k];
         bool any = false;
         for (size_t h = 0; h < g.hap_len.size(); h++) {
@@ -362,7 +374,7 @@ struct Driver {
     }
     for (size_t k = 0; k < plan.segs.size(); k++) {
       const Segment& g = plan.segs[k];
-      if (!g.has_seq || g.read_count == 0) continue;
+      if (!g.has_seq || g.read_count <= 0) continue;   // (negative: what a weightless chromosome's NaN shares turn into)
       const double total = seg_weight(plan, g) + 2.2204e-16;
       const uint32_t first = (uint32_t)wins.size();
       const uint64_t slot0 = slot;

@@ -106,7 +106,7 @@ def test_random_configuration(case_seed, oracle_lib, tmp_path):
         if rng.random() < 0.2:
             env["SG_SLOWQ_CAP"] = str(rng.choice([1, 64, 4096]))
     r = subprocess.run([SIMU, cfg, "--seed", str(seed), "--out", gdir, "--quiet", *extra], capture_output=True, text=True, timeout=120, env=env)
-    if rc != 0:   # whatever the oracle refuses (e.g. a zero-weight genome) the GPU path must refuse too
+    if rc != 0:   # whatever the oracle refuses (e.g. a copy-number gain on a haploid genome) the GPU path must refuse too
         assert r.returncode != 0, (oracle_lib.orc_last_error().decode(), r.stderr[-500:])
         return
     assert r.returncode == 0, r.stderr[-2000:]
