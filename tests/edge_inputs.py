@@ -35,7 +35,25 @@ WGS_VARIANTS = {
     "insert_below_read_length": dict(insertSize=60), "insert_equal_read_length": dict(insertSize=74), "insert_5000": dict(insertSize=5000),
     "ploidy_4": dict(ploidy=4), "ploidy_1_with_cn_gain": dict(ploidy=1), "layout_se": dict(layout="SE"), "threads_0": dict(threads=0),
 }
-NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6))
+
+
+def _variation_variants(rows):
+    popu, chrom = rows[0].split("\t")[1:3]
+    return {
+        "variation_file_empty": [],
+        "variation_insertion_at_1": rows + [f"i\t{popu}\t{chrom}\t1\tACGT\thomo"],
+        "variation_insertion_past_the_end": rows + [f"i\t{popu}\t{chrom}\t1000000000\tACGT\thomo"],
+        "variation_deletion_past_the_end": rows + [f"d\t{popu}\t{chrom}\t999999990\t50\thomo"],
+        "variation_on_absent_chromosome": rows + [f"i\t{popu}\tchrQ\t5000\tACGT\thomo"],
+        "variation_rows_twice": rows + rows,
+        "variation_lower_case_insertion": rows + [f"i\t{popu}\t{chrom}\t7000\tacgtn\thet"],
+        "variation_unknown_population": rows + [f"i\tnobody\t{chrom}\t5000\tACGT\thomo"],
+        "variation_short_row": rows + [f"s\t{popu}\t{chrom}\t5000\tA\thomo"],
+    }
+
+
+_VARIATION_NAMES = sorted(_variation_variants(["i\tp\tc\t1\tA\thomo"]))
+NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"]
 
 
 def build(name, workdir):
@@ -44,6 +62,20 @@ def build(name, workdir):
     if name in WGS_VARIANTS:
         base = cases.build_case("wgs_pe_variants", os.path.join(workdir, "base"))
         text = _edit(open(base).read(), **WGS_VARIANTS[name])
+    elif name in _VARIATION_NAMES or name == "snp_on_absent_chromosome":
+        base = cases.build_case("wgs_pe_variants", os.path.join(workdir, "base"))
+        text = open(base).read()
+        if name == "snp_on_absent_chromosome":
+            sp = os.path.join(workdir, "snp.txt")
+            with open(sp, "w") as f:
+                f.write("chrQ\t100\trs1\tA\tG\t0.5\n")
+            text = _edit(text, snp=sp)
+        else:
+            rows = _variation_variants(open(os.path.join(workdir, "base", "variations.txt")).read().splitlines())[name]
+            vp = os.path.join(workdir, "variations.txt")
+            with open(vp, "w") as f:
+                f.write("\n".join(rows) + ("\n" if rows else ""))
+            text = _edit(text, variation=vp)
     else:
         base = cases.build_case("wes_pe_targets", os.path.join(workdir, "base"))
         bed = open(os.path.join(workdir, "base", "targets.bed")).read().splitlines()
