@@ -52,8 +52,18 @@ def _variation_variants(rows):
     }
 
 
+ABUNDANCE_VARIANTS = {   # rows of the abundance file of the four-population mixture case (one mixture per row)
+    "abundance_sum_below_1": ["1.0\t0\t0\t0", "0.1\t0.1\t0.1\t0.1"],
+    "abundance_sum_above_1": ["1.0\t0\t0\t0", "0.5\t0.5\t0.5\t0.5"],
+    "abundance_zero_entry": ["1.0\t0\t0\t0", "0.5\t0\t0.25\t0.25"],
+    "abundance_three_columns": ["1.0\t0\t0\t0", "0.5\t0.25\t0.25"],
+    "abundance_five_columns": ["1.0\t0\t0\t0", "0.2\t0.2\t0.2\t0.2\t0.2"],
+    "abundance_negative_entry": ["1.0\t0\t0\t0", "0.7\t-0.1\t0.2\t0.2"],
+    "abundance_one_row": ["1.0\t0\t0\t0"],
+    "abundance_three_rows": ["1.0\t0\t0\t0", "0.3\t0.25\t0.35\t0.1", "0.25\t0.25\t0.25\t0.25"],
+}
 _VARIATION_NAMES = sorted(_variation_variants(["i\tp\tc\t1\tA\thomo"]))
-NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"]
+NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"] + sorted(ABUNDANCE_VARIANTS)
 
 
 def build(name, workdir):
@@ -62,6 +72,12 @@ def build(name, workdir):
     if name in WGS_VARIANTS:
         base = cases.build_case("wgs_pe_variants", os.path.join(workdir, "base"))
         text = _edit(open(base).read(), **WGS_VARIANTS[name])
+    elif name in ABUNDANCE_VARIANTS:
+        base = cases.build_case("tumor_se_mixture", os.path.join(workdir, "base"))
+        ap = os.path.join(workdir, "abundance.txt")
+        with open(ap, "w") as f:
+            f.write("\n".join(ABUNDANCE_VARIANTS[name]) + "\n")
+        text = _edit(open(base).read(), abundance=ap)
     elif name in _VARIATION_NAMES or name == "snp_on_absent_chromosome":
         base = cases.build_case("wgs_pe_variants", os.path.join(workdir, "base"))
         text = open(base).read()
