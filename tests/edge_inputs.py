@@ -62,8 +62,34 @@ ABUNDANCE_VARIANTS = {   # rows of the abundance file of the four-population mix
     "abundance_one_row": ["1.0\t0\t0\t0"],
     "abundance_three_rows": ["1.0\t0\t0\t0", "0.3\t0.25\t0.35\t0.1", "0.25\t0.25\t0.25\t0.25"],
 }
+
+
+def _fasta_variants():
+    """FASTA files fastahack indexes (Fasta.cpp:45-85) in shapes the ingest kernels have to cope with."""
+    from simuscop_amd import synth
+    a = synth.synth_contig(30000, 77, 0, n_runs=False).tobytes()
+    b = synth.synth_contig(21000, 77, 1, n_runs=False).tobytes()
+
+    def wrap(seq, w, eol=b"\n"):
+        return b"".join(seq[i:i + w] + eol for i in range(0, len(seq), w))
+
+    return {
+        "fasta_lf": [b">chr1\n", wrap(a, 60), b">chr2\n", wrap(b, 60)],
+        "fasta_crlf": [b">chr1\r\n", wrap(a, 60, b"\r\n"), b">chr2\r\n", wrap(b, 60, b"\r\n")],
+        "fasta_header_with_description": [b">chr1 some description here\n", wrap(a, 60), b">chr2 other\n", wrap(b, 60)],
+        "fasta_one_line_per_contig": [b">chr1\n", a + b"\n", b">chr2\n", b + b"\n"],
+        "fasta_no_final_newline": [b">chr1\n", wrap(a, 60), b">chr2\n", wrap(b, 60)[:-1]],
+        "fasta_blank_line_between_contigs": [b">chr1\n", wrap(a, 60), b"\n", b">chr2\n", wrap(b, 60)],
+        "fasta_lower_case": [b">chr1\n", wrap(a.lower(), 60), b">chr2\n", wrap(b, 60)],
+        "fasta_empty_contig": [b">chr1\n", wrap(a, 60), b">chr3\n", b">chr2\n", wrap(b, 60)],
+        "fasta_trailing_space": [b">chr1\n", wrap(a, 60, b" \n"), b">chr2\n", wrap(b, 60)],
+    }
+
+
+_FASTA_NAMES = ["fasta_blank_line_between_contigs", "fasta_crlf", "fasta_lf", "fasta_empty_contig", "fasta_header_with_description", "fasta_lower_case",
+                "fasta_no_final_newline", "fasta_one_line_per_contig", "fasta_trailing_space"]
 _VARIATION_NAMES = sorted(_variation_variants(["i\tp\tc\t1\tA\thomo"]))
-NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"] + sorted(ABUNDANCE_VARIANTS)
+NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"] + sorted(ABUNDANCE_VARIANTS) + _FASTA_NAMES
 
 
 def build(name, workdir):
@@ -72,6 +98,12 @@ def build(name, workdir):
     if name in WGS_VARIANTS:
         base = cases.build_case("wgs_pe_variants", os.path.join(workdir, "base"))
         text = _edit(open(base).read(), **WGS_VARIANTS[name])
+    elif name in _FASTA_NAMES:
+        fa = os.path.join(workdir, "ref.fa")
+        with open(fa, "wb") as f:
+            f.write(b"".join(_fasta_variants()[name]))
+        text = (f"ref = {fa}\nprofile = {os.path.join(cases.TESTDATA, cases.PROFILES['xten'])}\nname = fa\noutput = x\nlayout = PE\n"
+                f"threads = 1\nverbose = 0\ncoverage = 3\ninsertSize = 350\n")
     elif name in ABUNDANCE_VARIANTS:
         base = cases.build_case("tumor_se_mixture", os.path.join(workdir, "base"))
         ap = os.path.join(workdir, "abundance.txt")
@@ -105,3 +137,11 @@ def build(name, workdir):
     with open(cfg, "w") as f:
         f.write(text)
     return cfg
+
+
+# The one place where the GPU path deliberately does NOT follow the oracle (and the reference): a FASTA with CRLF line
+# ends.  fastahack keeps the carriage returns -- in the contig names ("@fa#1\r#69#1/1") and, one per line, in the
+# sequence, where they count as unknown bases (Fasta.cpp:150-199: line_blen includes them) -- so nearly every window
+# holds a non-ACGT byte and the run degenerates.  The oracle restates that (it is pinned on the binary); the product
+# reads such a file like its LF twin (test_gpu_edge_inputs.py checks exactly that).
+GPU_NAMES = [n for n in NAMES if n != "fasta_crlf"]
