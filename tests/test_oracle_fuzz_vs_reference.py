@@ -5,7 +5,7 @@ The committed golden sums pin named cases; this test draws configurations from t
 BED targets incl. overlapping / nested / unsorted ones, mixtures, derived read lengths and indel rates) and runs both
 programs on each, here and now.  It needs oracle/_ref/simuReads (built from /root/reference by `make -C oracle ref`, this
 container only); elsewhere it is skipped.  SIMU_REF_FUZZ_SEEDS=a-b widens it: seeds 101-148, 201-260 and 1001-1030 -- all
-138 seeds of the GPU fuzz -- and 300-999, 1031-2230 were run this way in round 3: 2,037 byte-identical (592 -- one target
+138 seeds of the GPU fuzz -- and 300-999, 1031-2710 were run this way in round 3: 2,517 byte-identical (592 -- one target
 inside an N run: a genome without weighted length -- after the oracle stopped refusing what the binary samples nothing
 from), one (1021: a copy-number gain on a haploid genome) is the documented case the reference never returns from."""
 import hashlib
