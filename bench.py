@@ -30,6 +30,7 @@ import sys
 import tempfile
 import threading
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -223,6 +224,9 @@ def main():
     ap.add_argument("--profile", default="xten", choices=sorted(PROFILES),
                     help="sequencing profile of the workload (default: HiSeqXTen, the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="make a process group even for ONE rank (also SIMUSCOP_FORCE_PG=1): the all_gather of the read balancing, "
+                         "the max/sum all-reduces and the strong leg's exchange then run through RCCL on the one GPU at hand")
     ap.add_argument("--strong-scale", type=float, default=None,
                     help="c2: size of the genome of the strong-scaling leg (24 contigs, GRCh38 lengths x this; default 1.0, 0.25 on hosts "
                          "with fewer than 16 cores; 0 = no leg)")
@@ -254,15 +258,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-
     import simuscop_amd
+    from simuscop_amd import dist as sdist
     from simuscop_amd import synth
+    # one group for the whole run, with a timeout: a rank that dies takes the others out of their collective after
+    # SIMUSCOP_PG_TIMEOUT_S (120 s) instead of leaving them there until the launcher's own limit
+    pg = sdist.init_process_group(args.backend, local_rank, world, force=args.force_process_group)
 
     workdir = tempfile.mkdtemp(prefix=f"simuscop_bench_r{rank}_")
     fasta = os.path.join(workdir, "ref.fa")
@@ -286,7 +287,6 @@ def main():
     L = PROFILES[args.profile][1]
     # ---- read-count balancing (Genome::setReadCounts) ----
     my_wl = sess.weighted_length()
-    from simuscop_amd import dist as sdist
     # all_gather of one fp64 pair per rank (RCCL over xGMI), then the reference's apportioning formula
     my_reads, _ = sdist.balance_reads(my_wl, args.contig_len, args.coverage, L, device=coll_dev)
     sess.set_reads(my_reads)
@@ -305,7 +305,7 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -320,11 +320,11 @@ def main():
             kms[k] += v
     queued_items = sess.emit_info()[0]   # of the last pass
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     dt = time.perf_counter() - t0
 
-    if world > 1:
+    if pg:
         t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=coll_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -418,15 +418,55 @@ def main():
                 out["host_pinned"] = None
                 out["host_pinned_error"] = repr(e)
         out["value_device_resident"] = out["value"]
+        # what a step spends outside its kernels (launch gaps, event records, the host's wait for the pass): the headline is a
+        # step rate, the roofline a kernel rate -- the line says how far apart the two are
+        ksum = sum(out["kernel_ms_per_step"].values())
+        out["gap_ms_per_step"] = out["ms_per_step"] - ksum
+        out["step_over_kernels"] = out["ms_per_step"] / ksum if ksum else None
+        out["roofline"]["frac_at_step_level"] = pairs_per_step * bytes_per_pair / (out["ms_per_step"] * 1e-3) / 1e9 / 8000.0
+        if world == 1 and not args.no_cpu_baseline:
+            # (before the strong leg: with one rank no collective can hang it, and the line below stays the only one)
+            try:
+                out["cpu_baseline"] = cpu_baseline(workdir, PROFILES[args.profile][0])
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = None
+                out["cpu_baseline_error"] = repr(e)
+        if world > 1 and strong_scale:
+            # N > 1: the weak-scaling line leaves NOW, flushed.  The strong leg below is a second whole measurement with
+            # collectives of its own; whatever happens to it, the driver has this line.  The full line (this one plus
+            # `strong_c3`) follows as the last line of the run.
+            print(json.dumps(dict(out, line="weak-scaling result; the full line (with strong_c3) follows the strong leg")), flush=True)
     sess.close()
     del sess
     # ---- strong scaling of ONE genome (BASELINE configs[3]) in the same line: every N, the flag-less run included ----
+    rc = 0
     if strong_scale:
         import bench_c3
+        # Every rank says whether it can enter the leg (its genome is on disk, its engine is alive); one "no" keeps ALL
+        # ranks out of it -- alike, so nobody is left in a collective.
+        ready = 1.0
         try:
-            leg = bench_c3.measure("c3", strong_scale, max(1, min(args.steps, 3)), 1, "xten", None, args.backend, rank, local_rank, world)
-        except Exception as e:  # noqa: BLE001 -- the leg must not cost the line
-            leg = {"error": repr(e)}
+            if not os.path.exists(bench_c3.genome_path(strong_scale) + ".fai"):
+                ready = 0.0
+        except Exception:  # noqa: BLE001
+            ready = 0.0
+        if pg:
+            flag = torch.tensor([ready], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ready = float(flag[0])
+        leg = {"error": "a rank was not ready for the strong leg (genome missing)"}
+        if ready:
+            try:
+                leg = bench_c3.measure("c3", strong_scale, max(1, min(args.steps, 3)), 1, "xten", None, args.backend, rank, local_rank, world)
+            except Exception as e:  # noqa: BLE001
+                traceback.print_exc()
+                sys.stderr.flush()
+                if pg and world > 1:
+                    # The other ranks are inside (or about to enter) a collective of the leg that this rank will never
+                    # join.  The weak line is out already; leave with a non-zero code so that the launcher ends the others
+                    # (and their group timeout does if it does not) -- never re-enter, never re-exec.
+                    os._exit(3)
+                leg = {"error": repr(e)}   # one rank: nothing waits for us, the line survives with the error in it
         if rank == 0:
             if isinstance(leg, dict) and "value" in leg:
                 leg = {"value": leg["value"], "unit": leg["unit"], "scaling": "strong", "n_gpus": world, "s_per_run": leg["ms_per_step"] / 1e3,
@@ -434,18 +474,21 @@ def main():
                        "per_rank": leg["per_rank"], "emit_roofline_frac": leg["roofline"]["frac"]}
             out["strong_c3"] = leg
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(workdir, PROFILES[args.profile][0])
-            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
-                out["cpu_baseline"] = None
-                out["cpu_baseline_error"] = repr(e)
+        if pg:
+            out["process_group"] = {"backend": "rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend, "world": world,
+                                    "timeout_s": sdist.pg_timeout_s(), "exchange_collectives_rank0": dict(sdist.COLLECTIVES)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if pg:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 -- a peer that left early: the lines are out, say so with the exit code
+            traceback.print_exc()
+            rc = 4
     import shutil
     shutil.rmtree(workdir, ignore_errors=True)
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -82,12 +82,8 @@ def main(args):
     if os.environ.get("BENCH_SAME_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+    from simuscop_amd import dist as sdist
+    pg = sdist.init_process_group(args.backend, local_rank, world, force=getattr(args, "force_process_group", False))
     out = measure(args.workload, args.scale, args.steps, args.warmup, args.profile, args.coverage, args.backend, rank, local_rank, world)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -99,7 +95,7 @@ def main(args):
                 out["cpu_baseline"] = None
                 out["cpu_baseline_error"] = repr(e)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -115,8 +111,10 @@ def measure(workload, scale, steps, warmup, profile, coverage, backend, rank, lo
     from simuscop_amd import dist as sdist
     from simuscop_amd import synth
 
+    pg = sdist.group_active()   # (also a one-rank group made with --force-process-group: every collective below then runs)
+
     def barrier():
-        if world > 1:
+        if pg:
             dist.barrier()
 
     fasta, contigs = genome_path(scale), synth.grch38_contigs(scale)
@@ -134,7 +132,7 @@ def measure(workload, scale, steps, warmup, profile, coverage, backend, rank, lo
             f.write(text + f"variation = {extra['variation']}\nsnp = {extra['snp']}\nabundance = {extra['abundance']}\n")
     opts = dict(device=local_rank, quiet=1, write_files=0, seed=0x5EED0C3, shard_rank=rank, shard_world=world)
     exchange = None
-    if world > 1:
+    if pg:
         exchange = sdist.make_exchange("cuda" if backend == "nccl" else None)
         opts.update(shard_contigs=1, exchange=exchange)
 
@@ -158,7 +156,7 @@ def measure(workload, scale, steps, warmup, profile, coverage, backend, rank, lo
     kernel_ms = {n: float(last.kernel_ms[i]) for i, n in enumerate(simuscop_amd.SG_K_NAMES)}
     mine = {"rank": rank, "dt": dt, "pairs": frags, "bytes": int(last.fastq_bytes), "phases": phases, "kernel_ms": kernel_ms,
             "work": {"windows": int(last.windows), "segments": int(last.segments), "batches": int(last.batches)}}
-    if world > 1:
+    if pg:
         allv = [None] * world
         dist.all_gather_object(allv, mine)
     else:

@@ -51,6 +51,12 @@ const char* sg_last_error(const sg_ctx* ctx); /* ctx may be NULL: error of a fai
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
 int sg_set_stream(sg_ctx* ctx, void* hip_stream);
 int sg_set_seed(sg_ctx* ctx, uint64_t seed);
+/* A literal 'X' in the genome.  The reference's k-mer trie files the short contexts of a read's first bases under the
+ * character 'X' ("XXb", "Xbb": Profile::initKmers, lib/profile/Profile.cpp:94-101) and Profile::getKmerIndx (:220-226)
+ * walks it with whatever the template holds, so an X of the genome acts as that place holder in the middle of a read
+ * (on forward reads: Segment::getComplementSeq turns it into 'N', lib/segment/Segment.cpp:99).  Default 0: the same here.
+ * 1 (`simuReads --strict-bases`): an X is an unknown base like any other non-ACGT character.                          */
+int sg_set_strict_bases(sg_ctx* ctx, int on);
 
 /* ---- profile tables ---------------------------------------------------------------------- */
 /* The products of Profile::train(file) (lib/profile/Profile.cpp:1436-1440) exactly as the

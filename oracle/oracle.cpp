@@ -839,7 +839,7 @@ struct Fasta {
   void open(const string& file) {
     std::ifstream ifs(file.c_str());
     if (!ifs.is_open()) throw Fail("could not open " + file);
-    string line, cur;
+    string line, cur, ignored;
     string* dst = nullptr;
     while (std::getline(ifs, line)) {
       if (!line.empty() && line[0] == ';') continue;
@@ -847,8 +847,17 @@ struct Fasta {
         string full = line.substr(1);
         vector<string> toks = split_any(full, " \t");
         string name = abbrOfChr(toks.empty() ? string("") : toks[0]);
-        if (!seqs.count(name)) names.push_back(name);
-        dst = &seqs[name];
+        // A name met again: fastahack lists it once more (sequenceNames.push_back, Fasta.cpp:66,197) but its map keeps the
+        // FIRST entry (std::map::insert does not overwrite, Fasta.cpp:67,198), and the index it writes and reads back is
+        // sorted by offset (Fasta.cpp:84-97) -- the row of the first sequence, twice, at the first one's place.  The
+        // chromosome list then holds the name twice, both resolving to the first sequence; the later one is never read.
+        if (seqs.count(name)) {
+          names.insert(std::find(names.begin(), names.end(), name) + 1, name);
+          dst = &ignored;
+        } else {
+          names.push_back(name);
+          dst = &seqs[name];
+        }
         dst->clear();
       } else if (dst) {
         dst->append(line);

@@ -20,7 +20,7 @@ SG_K_NAMES = ["plan", "namebase", "indel", "scan", "emit", "emit_slow"]
 
 # every symbol include/simuscop_amd.h declares
 ENGINE_SYMBOLS = [
-    "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_load_profile",
+    "sg_create", "sg_destroy", "sg_last_error", "sg_set_stream", "sg_set_seed", "sg_set_strict_bases", "sg_load_profile",
     "sg_upload_haplotypes", "sg_reference_begin", "sg_reference_chunk", "sg_sync", "sg_reference_scan",
     "sg_reference_commit", "sg_build_haplotypes", "sg_haplotype_codes", "sg_compress", "sg_fetch_compressed",
     "sg_bgzf_eof", "sg_deflate_plan", "sg_detach_outputs", "sg_outputs_sizes", "sg_outputs_fetch",
@@ -85,7 +85,8 @@ class SimuOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("has_seed", C.c_int32), ("seed", C.c_uint64), ("write_files", C.c_int32),
                 ("fetch", C.c_int32), ("quiet", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("output_dir", C.c_char_p), ("repeat_sample", C.c_int32), ("host_haplotypes", C.c_int32), ("gzip", C.c_int32),
-                ("shard_contigs", C.c_int32), ("no_eof_block", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
+                ("shard_contigs", C.c_int32), ("no_eof_block", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p),
+                ("crlf_as_lf", C.c_int32), ("strict_bases", C.c_int32), ("unique_contigs", C.c_int32)]
 
 
 # simu_options.exchange: all-reduce(sum) of n doubles over the ranks, in place

@@ -30,11 +30,12 @@ static std::string plain_path(const std::string& ref_file) {
   return path;
 }
 
-static std::string header_key(const std::string& header) {  // Fasta.cpp:58-69
+static std::string header_key(const std::string& header, bool crlf_as_lf) {  // Fasta.cpp:58-69
   size_t b = header.find_first_not_of(" \t");
   std::string tok;
   if (b != std::string::npos) {
-    size_t e = header.find_first_of(" \t\r", b);
+    // (the reference cuts the name at blanks and tabs only: the carriage return of a CR LF file stays in it)
+    size_t e = header.find_first_of(crlf_as_lf ? " \t\r" : " \t", b);
     tok = header.substr(b, e == std::string::npos ? std::string::npos : e - b);
   }
   return abbr_of_chr(tok);
@@ -85,7 +86,7 @@ std::string pread_string(int fd, uint64_t off, uint64_t n) {
 // a few small preads per contig -- header text, first line (bases / bytes per line), last bytes.  False when a
 // contig's body cannot be a run of equal-width lines.
 bool rows_from_headers(int fd, uint64_t size, const std::vector<uint64_t>& hdr, std::vector<std::string>& keys,
-                       std::vector<FastaContig>& rows) {
+                       std::vector<FastaContig>& rows, bool crlf_as_lf) {
   for (size_t i = 0; i < hdr.size(); i++) {
     const uint64_t region_end = i + 1 < hdr.size() ? hdr[i + 1] : size;
     // header line
@@ -123,6 +124,9 @@ bool rows_from_headers(int fd, uint64_t size, const std::vector<uint64_t>& hdr, 
         if (nl != std::string::npos) {
           const uint64_t at = q + nl;  // file offset of the '\n'
           const bool cr = at > first && (nl > 0 ? blk[nl - 1] == '\r' : pread_string(fd, at - 1, 1) == "\r");
+          // carriage returns that stay bases (the reference's reading): not a file of fixed-width lines of bases only --
+          // the general parser takes it
+          if (cr && !crlf_as_lf) return false;
           lb = at - first - (cr ? 1 : 0);
           lw = at - first + 1;
           found_nl = true;
@@ -138,12 +142,20 @@ bool rows_from_headers(int fd, uint64_t size, const std::vector<uint64_t>& hdr, 
     } else {
       row.line_bases = row.line_width = 1;
     }
-    keys.push_back(header_key(head));
+    if (!crlf_as_lf && head.find('\r') != std::string::npos) return false;
+    keys.push_back(header_key(head, crlf_as_lf));
     rows.push_back(row);
   }
   return true;
 }
 }  // namespace
+
+bool Fasta::note_name(const std::string& key, bool seen) {
+  if (!seen) { names.push_back(key); return false; }
+  if (unique_contigs) throw Error("ERROR: contig name " + key + " stands more than once in the reference sequence file (--unique-contigs)");
+  names.insert(std::find(names.begin(), names.end(), key) + 1, key);   // next to its first place (the index is sorted by offset)
+  return true;
+}
 
 void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads) {
   const std::string path = plain_path(ref_file);
@@ -201,7 +213,7 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
     bool uniform = !(flags & 1u) && found > 0;
     std::vector<std::string> keys;
     std::vector<FastaContig> rows;
-    if (uniform) uniform = rows_from_headers(fd, size, hdr, keys, rows);
+    if (uniform) uniform = rows_from_headers(fd, size, hdr, keys, rows, crlf_as_lf);
     if (uniform) {
       std::vector<sg_contig> tab;
       for (const FastaContig& r : rows) tab.push_back(sg_contig{r.raw_offset, r.length, r.line_bases, r.line_width});
@@ -211,9 +223,8 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
     }
     if (uniform) {
       contigs = rows;
-      for (size_t i = 0; i < keys.size(); i++) {  // a repeated name keeps its first place and its last sequence
-        if (!contig_of.count(keys[i])) names.push_back(keys[i]);
-        contig_of[keys[i]] = (uint32_t)i;
+      for (size_t i = 0; i < keys.size(); i++) {  // (a repeated name: listed again, resolved to its first sequence)
+        if (!note_name(keys[i], contig_of.count(keys[i]) != 0)) contig_of[keys[i]] = (uint32_t)i;
       }
       streamed = true;
       ok = true;
@@ -235,6 +246,7 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
     uint64_t total = 0;
     std::vector<sg_contig> tab;
     for (const std::string& k : names) {
+      if (contig_of.count(k)) continue;   // (a repeated name: one sequence, listed twice)
       const std::string& s = seqs.at(k);
       contig_of[k] = (uint32_t)contigs.size();
       FastaContig row;
@@ -246,9 +258,9 @@ void Fasta::open_on_device(const std::string& ref_file, sg_ctx* ctx, int threads
       total += s.size();
     }
     eng_check(ctx, sg_reference_begin(ctx, total), "sg_reference_begin");
-    for (const std::string& k : names) {
-      const std::string& s = seqs.at(k);
-      eng_check(ctx, sg_reference_chunk(ctx, contigs[contig_of[k]].raw_offset, s.data(), s.size()), "sg_reference_chunk");
+    for (const auto& kv : contig_of) {
+      const std::string& s = seqs.at(kv.first);
+      eng_check(ctx, sg_reference_chunk(ctx, contigs[kv.second].raw_offset, s.data(), s.size()), "sg_reference_chunk");
     }
     eng_check(ctx, sg_sync(ctx), "sg_sync");
     eng_check(ctx, sg_reference_commit(ctx, tab.data(), (uint32_t)tab.size()), "sg_reference_commit");
@@ -265,6 +277,7 @@ void Fasta::open(const std::string& ref_file) {
   names.clear();
   seqs.clear();
   std::string* cur = nullptr;
+  std::string ignored;   // the sequence under a repeated name is never read (note_name)
   std::vector<char> buf(1 << 22);
   std::string header;
   bool in_header = false, line_start = true, skip_line = false;
@@ -280,9 +293,8 @@ void Fasta::open(const std::string& ref_file) {
         p = nl + 1;
         if (in_header) {
           in_header = false;
-          std::string key = header_key(header);
-          if (!seqs.count(key)) names.push_back(key);
-          cur = &seqs[key];
+          std::string key = header_key(header, crlf_as_lf);
+          cur = note_name(key, seqs.count(key) != 0) ? &ignored : &seqs[key];
           cur->clear();
           header.clear();
         }
@@ -296,7 +308,7 @@ void Fasta::open(const std::string& ref_file) {
       }
       const char* nl = (const char*)memchr(p, '\n', end - p);
       const char* stop = nl ? nl : end;
-      if (nl && stop > p && stop[-1] == '\r') stop--;  // CRLF files: the index arithmetic (LINEBASES) excludes it too
+      if (crlf_as_lf && nl && stop > p && stop[-1] == '\r') stop--;  // --crlf-as-lf; by default the carriage return stays, as a base (fasta.h)
       if (cur && stop > p) {
         size_t old = cur->size();
         cur->append(p, stop - p);
@@ -313,6 +325,7 @@ void Fasta::open(const std::string& ref_file) {
   if (names.empty()) throw Error("ERROR: reference sequence cannot be empty!");
   contigs.clear(); contig_of.clear();
   for (const std::string& k : names) {  // index rows (lengths only: no file offsets in this mode)
+    if (contig_of.count(k)) continue;
     contig_of[k] = (uint32_t)contigs.size();
     FastaContig row;
     row.length = seqs.at(k).size();
@@ -366,7 +379,10 @@ bool Fasta::load_index(const std::string& ref_file, int threads) {
         const char* line = hb + h + 1;
         if (*line != '>') { ok = false; break; }
         std::string name(line + 1, (size_t)((hb + back - 1) - (line + 1)));
-        if (!name.empty() && name.back() == '\r') name.pop_back();
+        if (!name.empty() && name.back() == '\r') {
+          if (!crlf_as_lf) { ok = false; break; }   // carriage returns that stay in names and bases: the general parser's case
+          name.pop_back();
+        }
         name = name.substr(0, name.find_first_of(" \t"));
         if (abbr_of_chr(name) != keys[i]) { ok = false; break; }
         if (end < size) {
@@ -419,14 +435,19 @@ bool Fasta::load_index(const std::string& ref_file, int threads) {
     bool plain = true;
     for (int t = 0; t < nt; t++) { plain &= !odd[(size_t)t]; hdr.insert(hdr.end(), found[(size_t)t].begin(), found[(size_t)t].end()); }
     std::sort(hdr.begin(), hdr.end());
-    ok = plain && !hdr.empty() && rows_from_headers(fd, size, hdr, keys, rows);
+    ok = plain && !hdr.empty() && rows_from_headers(fd, size, hdr, keys, rows, crlf_as_lf);
   }
   ::close(fd);
+  if (ok) {   // a repeated name: ownership is by name, so such a file is ingested whole by every rank (open_on_device)
+    std::vector<std::string> sorted_keys = keys;
+    std::sort(sorted_keys.begin(), sorted_keys.end());
+    if (std::adjacent_find(sorted_keys.begin(), sorted_keys.end()) != sorted_keys.end()) ok = false;
+  }
   if (!ok) return false;
   on_device = true;
   names.clear(); seqs.clear(); contigs = rows; contig_of.clear(); dev_row.clear();
-  for (size_t i = 0; i < keys.size(); i++) {  // a repeated name keeps its first place and its last sequence
-    if (!contig_of.count(keys[i])) names.push_back(keys[i]);
+  for (size_t i = 0; i < keys.size(); i++) {
+    names.push_back(keys[i]);
     contig_of[keys[i]] = (uint32_t)i;
   }
   return true;

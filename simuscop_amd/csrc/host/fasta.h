@@ -21,7 +21,18 @@ struct FastaContig {  // one row of the index (what a .fai line holds, Fasta.cpp
 };
 
 struct Fasta {
-  std::vector<std::string> names;            // file order
+  // Two things fastahack does with odd files are kept by default (quirks reproduced, fixes behind additive
+  // flags); the oracle restates both and is pinned on the reference binary (tests/edge_inputs.py):
+  //  * CR LF line ends: getline() cuts at '\n' only, so the carriage returns stay -- one per line in the sequence, where
+  //    they are unknown bases, and at the end of every contig name (Fasta.cpp:150-199).  `crlf_as_lf` (--crlf-as-lf)
+  //    reads such a file like its LF twin instead.
+  //  * a contig name met again: listed once more, but the index keeps the FIRST entry (std::map::insert, Fasta.cpp:67,198)
+  //    and is written and read back sorted by offset (Fasta.cpp:84-97): the name stands twice in the chromosome list,
+  //    next to its first place, and both resolve to the first sequence.  `unique_contigs` (--unique-contigs) refuses
+  //    such a file.
+  bool crlf_as_lf = false;
+  bool unique_contigs = false;
+  std::vector<std::string> names;            // index order (a repeated name: see above)
   std::map<std::string, std::string> seqs;   // upper-cased bases (host mode only)
   // device mode: the file lives in HBM as base codes (sg_reference_*), the host keeps the index only
   bool on_device = false;
@@ -32,6 +43,8 @@ struct Fasta {
   // but only the owned ones are on this device; dev_row = row of the table given to sg_reference_commit, or -1
   std::vector<int32_t> dev_row;
 
+  // a header's key met again: the reference's place for it in `names` (or the refusal); true when it is a repeat
+  bool note_name(const std::string& key, bool seen);
   void open(const std::string& path);        // handles the reference's `.gz` convention (Genome.cpp:224-228)
   // Streams the file to the engine (`threads` readers, two pinned staging buffers), finds the headers
   // with the device scan, reads only the header lines on the host.  Files the arithmetic ingest cannot

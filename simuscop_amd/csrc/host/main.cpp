@@ -2,6 +2,7 @@
 // Same positional argument, usage text and exit codes; optional flags are additive:
 //   --seed N  --device D  --out DIR  --no-write [--fetch]  --quiet  --rank R --world W  --stats  --host-haplotypes  --gzip
 //   --gpus N [--shard-contigs]
+//   --crlf-as-lf  --strict-bases  --unique-contigs   (each turns one kept reference quirk off: simulate.h)
 #include <dirent.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -224,6 +225,9 @@ int main(int argc, char* argv[]) {
     else if (a == "--gzip") opt.gzip = 1;
     else if (a == "--shard-contigs") opt.shard_contigs = 1;
     else if (a == "--no-eof-block") opt.no_eof_block = 1;
+    else if (a == "--crlf-as-lf") opt.crlf_as_lf = 1;
+    else if (a == "--strict-bases") opt.strict_bases = 1;
+    else if (a == "--unique-contigs") opt.unique_contigs = 1;
     else if (a == "--exchange-fds") {  // set by the --gpus parent: "<write fd>,<read fd>" of this child's pipe pair
       const char* v = val();
       static PipeExchange px;

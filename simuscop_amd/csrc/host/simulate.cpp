@@ -267,9 +267,11 @@ struct Driver {
         }
         chr_wl.push_back(c);
       }
-      if (!genome.owner_of.empty()) {
+      if (!genome.owner_of.empty() || (opt.shard_contigs && opt.exchange)) {
         // the other ranks' chromosomes: one small exchange per population (RCCL / gloo all-reduce in the torchrun front
-        // end, the parent's pipes under `simuReads --gpus N`); each entry has one owner, so the sum is exact
+        // end, the parent's pipes under `simuReads --gpus N`); each entry has one owner, so the sum is exact.  (A single
+        // rank that was handed an exchange runs it too -- the sum of one contribution -- so that the transport can be
+        // rehearsed on one GPU: tests/test_gpu_nccl_world1.py.)
         if (!opt.exchange) throw Error("ERROR: chromosome sharding needs an exchange callback (simu_options.exchange)");
         if (opt.exchange(opt.exchange_user, chr_wl.data(), (int32_t)chr_wl.size()) != 0)
           throw Error("ERROR: the weighted-length exchange between the ranks failed");
@@ -658,6 +660,9 @@ struct Driver {
     genome.device_haps = !opt.host_haplotypes;
     genome.engine = eng.ctx;
     genome.shard_rank = opt.shard_rank;
+    genome.fa.crlf_as_lf = opt.crlf_as_lf != 0;
+    genome.fa.unique_contigs = opt.unique_contigs != 0;
+    if (sg_set_strict_bases(eng.ctx, opt.strict_bases) != SG_OK) throw Error(std::string("GPU engine error: ") + sg_last_error(eng.ctx));
     genome.shard_world = opt.shard_world;
     genome.shard_contigs = opt.shard_contigs != 0 && opt.shard_world > 1;
     // The profile -- parsing its text (Profile::load / normParas / initCDFs), converting every CDF row into the engine's

@@ -32,6 +32,13 @@ typedef struct simu_options {
   // owner), so the sum is exact whatever the order.  Called once per population.  Returns 0 on success.
   int (*exchange)(void* user, double* values, int32_t n);
   void* exchange_user;
+  // Three reference quirks are kept by default; each flag is additive and turns ONE of them off:
+  int32_t crlf_as_lf;      // 1: a FASTA with CR LF line ends reads like its LF twin (default: the carriage returns stay, in the
+                           //    contig names and as one unknown base per line, as fastahack keeps them: Fasta.cpp:150-199)
+  int32_t strict_bases;    // 1: a literal 'X' in the genome is an unknown base (default: it walks the k-mer trie as the place
+                           //    holder of the short contexts, Profile.cpp:94-101, 220-226)
+  int32_t unique_contigs;  // 1: refuse a FASTA that holds a contig name twice (default: the name stands twice in the
+                           //    chromosome list and both resolve to the first sequence, Fasta.cpp:67,84-97,198)
 } simu_options;
 
 typedef struct simu_stats {

@@ -454,6 +454,12 @@ int sg_set_seed(sg_ctx* ctx, uint64_t seed) {
   return SG_OK;
 }
 
+int sg_set_strict_bases(sg_ctx* ctx, int on) {
+  if (!ctx) return SG_ERR_INVALID;
+  ctx->B.strict_bases = on ? 1u : 0u;   // read by the generic item code of every later pass (template_code, sg_kernels.hip)
+  return SG_OK;
+}
+
 int sg_set_profiling(sg_ctx* ctx, int enable) {
   if (!ctx) return SG_ERR_INVALID;
   SG_HIP(hipSetDevice(ctx->device));

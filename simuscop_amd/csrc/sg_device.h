@@ -87,6 +87,7 @@ struct DevBatch {
   uint32_t prefix_w[4];         // first 16 prefix bytes by value (longer prefixes fall back to the global copy)
   uint32_t k0, k1;              // philox key
   uint32_t diag;                // SG_DIAG timing ablations (0 in production; outputs are wrong otherwise)
+  uint32_t strict_bases;        // 1: a literal X of the genome is an unknown base (sg_set_strict_bases); 0: the trie's place holder
   // work buffers
   PairRec* pairs;               // [n_slots]
   uint32_t* win_actual;         // [n_windows] fragments actually produced per window

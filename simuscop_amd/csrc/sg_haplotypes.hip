@@ -15,11 +15,12 @@
 
 namespace sg {
 
-// base codes shared with sg_kernels.hip: A0 C1 T2 G3, 'N' = 4, anything else = 5
+// base codes shared with sg_kernels.hip: A0 C1 T2 G3, 'N' = 4, 'X' = 6 (the k-mer trie's place holder, template_code in
+// sg_kernels.hip), anything else = 5
 __device__ __forceinline__ uint32_t encode_base(uint32_t b) {
   if (b >= 'a' && b <= 'z') b -= 32u;  // Segment.cpp:143 (reference slice), :456 (variant alleles)
   const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
-  return acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : 5u);
+  return acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : (b == 'X' ? 6u : 5u));
 }
 
 // ---- header scan: offsets of '>' / '@' at a line start; ';' comment lines raise flag 1 ----------

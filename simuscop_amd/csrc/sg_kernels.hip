@@ -638,6 +638,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 #define EMIT_WAVES (EMIT_THREADS / 64)
 #define META_ROW 32  // bytes of LDS metadata per read
 
+// A template byte of the chains (A0 C1 T2 G3, N = 4, X = 6, anything else = 5) as the sampling loop sees it: a base code in
+// read orientation (reverse reads: complemented, A0 <-> T2, C1 <-> G3, Segment.cpp:81-103), 4 = unknown, 6 = a literal 'X'.
+// The reference's k-mer trie holds the place-holder contexts "XXb" and "Xbb" of a read's first bases under the character
+// 'X' (Profile.cpp:94-101), so a literal X in the genome -- on a forward read: the complement of anything but A/C/G/T is
+// 'N' (Segment.cpp:99) -- is the same place holder in the middle of a read.  `x_known` false (--strict-bases): an X is an
+// unknown base like any other.
+__device__ __forceinline__ uint32_t template_code(uint32_t raw, bool rev, bool x_known) {
+  return raw < 4u ? (rev ? raw ^ 2u : raw) : ((raw == 6u && !rev && x_known) ? 6u : 4u);
+}
+
 // Source codes of a read that carries sequencing-indel events (rare path, kept OUT OF LINE and
 // un-unrolled: inlined it pushed the kernel past the 64 KB instruction cache and cost 2x).
 // Walks the events of Profile::predict's first loop (Profile.cpp:1607-1658) with a forward cursor and
@@ -645,12 +655,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t* 
 // for reverse reads), 4/5 = not in `bases`, bit 3 set = inserted base (already a profile code).
 __device__ __noinline__ uint64_t slow_codes(const uint8_t* frag, uint32_t flen, uint32_t rev, const uint32_t* ev,
                                             uint32_t nev, uint32_t np, uint32_t i0, uint32_t K, uint32_t slot,
-                                            uint32_t ctx_aux, uint32_t k0, uint32_t k1) {
+                                            uint32_t ctx_aux, uint32_t k0, uint32_t k1, bool x_known) {
   uint64_t out = 0;
   uint32_t e = 0;
   int shift = 0;  // output index - template index of the template bases after the consumed events
   uint32_t nextw = nev ? ev[0] : 0xFFFFFFFFu;
-  const uint32_t revmask = rev ? 2u : 0u;
 #pragma unroll 1
   for (int q = 0; q < 13; q++) {
     const int p = (int)i0 - 5 + q;
@@ -682,7 +691,7 @@ __device__ __noinline__ uint64_t slow_codes(const uint8_t* frag, uint32_t flen, 
       }
       if (!inserted) {
         const uint32_t jt = (uint32_t)(p - shift);
-        v = ((uint32_t)frag[rev ? flen - 1u - jt : jt] ^ revmask) & 7u;
+        v = template_code(frag[rev ? flen - 1u - jt : jt], rev != 0u, x_known);
       }
     }
     out |= (uint64_t)v << (4 * q);
@@ -704,7 +713,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
   const uint32_t inv = m1.z;
   const uint8_t* frag = B.chains + (((uint64_t)m0.y << 32) | m0.x);
   const uint32_t i0 = 8u * c;
-  const uint32_t revmask = rev ? 2u : 0u;  // complement in code space: A0<->T2, C1<->G3 (Segment.cpp:81-103)
+  const bool x_known = B.strict_bases == 0u;  // a literal X of the genome is the trie's place holder (template_code)
 
   // ---- source codes for positions i0-5 .. i0+7 (index q = p - i0 + 5); >= 4 means "not in bases" ----
   // Every lane loads the un-shifted template window: 16 encoded haplotype bytes; after the conditional
@@ -724,7 +733,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     uint32_t w[4] = {0x00010203u + i0, 0x03020100u, 0x01000302u, 0x02030001u};
     if (!(B.diag & 2u)) load_window(src, w);
 #pragma unroll
-    for (int q = 0; q < 13; q++) code[q] = ((w[q >> 2] >> ((q & 3) * 8)) & 0xFFu) ^ revmask;
+    for (int q = 0; q < 13; q++) code[q] = template_code((w[q >> 2] >> ((q & 3) * 8)) & 0xFFu, rev, x_known);
   }
   // Reads with exactly one sequencing indel (most event reads): past the event the template window is
   // the same window shifted by +-len; inserted bases are redrawn from their addressed Philox stream.
@@ -740,7 +749,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
 #pragma unroll
       for (int q = 0; q < 13; q++) {
         const int p = (int)i0 - 5 + q;
-        const uint32_t c2 = ((w2[q >> 2] >> ((q & 3) * 8)) & 0xFFu) ^ revmask;
+        const uint32_t c2 = template_code((w2[q >> 2] >> ((q & 3) * 8)) & 0xFFu, rev, x_known);
         if (p >= first_shifted) code[q] = c2;
       }
       if (!del) {
@@ -765,7 +774,7 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     if (nev >= 2u) {
       const uint32_t* ev = B.events + ((size_t)m * B.n_slots + slot) * SG_MAX_EVENTS;
       const uint64_t packed = slow_codes(frag, flen, rev ? 1u : 0u, ev, nev, np, i0, K, slot + B.slot_offset,
-                                         dev_ctx(KIND_AUX, m, B.batch_id), B.k0, B.k1);
+                                         dev_ctx(KIND_AUX, m, B.batch_id), B.k0, B.k1, x_known);
 #pragma unroll
       for (int q = 0; q < 13; q++) {
         const uint32_t v = (uint32_t)(packed >> (4 * q)) & 0xFu;
@@ -782,16 +791,21 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     else if (!identity && v < 4u) v = (P.remap_packed >> (2u * v)) & 3u;
     code[q] = v;
   }
-  // ---- k-mer context of the K-1 positions before i0 (Profile::initKmers order, Profile.cpp:70-124) ----
-  uint32_t ctxv = 0, vc = 0;
+  // ---- k-mer context (Profile::initKmers order, Profile.cpp:70-124).  The reference looks the K characters ending at a
+  // position up in a trie that holds b^K and the place-holder forms X^a b^(K-a) (Profile.cpp:94-101, 220-226); the
+  // characters before a read's first base are 'X' (Profile.cpp:1660-1663), and so is a literal X of the genome.  A position
+  // has a context iff its window is a run of X (xr of them) followed by vc >= 1 bases; the context then has min(vc, K)
+  // bases.  State: vc = bases at the end of what was seen, xr = the X run right before them, xc = the X run at the end.
+  uint32_t ctxv = 0, vc = 0, xr = 0, xc = 0;
+  auto ctx_step = [&](uint32_t c) {
+    const bool valid = c < 4u;
+    ctxv = ((ctxv << 2) | (c & 3u)) & ctxmask;
+    if (valid) { if (vc == 0u) xr = xc; vc = min(vc + 1u, K); xc = 0u; }
+    else { vc = 0u; xr = 0u; xc = c == 6u ? min(xc + 1u, K) : 0u; }
+  };
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
-    if (q >= 6 - (int)K && (int)i0 - 5 + q >= 0) {
-      const bool valid = code[q] < 4u;
-      ctxv = ((ctxv << 2) | (code[q] & 3u)) & ctxmask;
-      vc = valid ? min(vc + 1u, K) : 0u;
-    }
-  }
+  for (int q = 0; q < 5; q++)
+    if (q >= 6 - (int)K) ctx_step((int)i0 - 5 + q >= 0 ? code[q] : 6u);   // the K-1 positions before i0
   // ---- four Philox calls: heads and tails of output positions i0 .. i0+7 (call = i/4, c2 = 0 heads / 1 tails, word = i%4):
   //   substitution draw = heads[31:16] << 16 | tails[31:16],  quality draw = heads[15:0] << 16 | tails[15:0]
   uint32_t xh[8], xt[8];
@@ -812,13 +826,12 @@ __device__ __forceinline__ void emit_item(const DevProfile& P, const DevBatch& B
     const uint32_t i = i0 + (uint32_t)h;
     const uint32_t cd = code[5 + h];
     const bool valid = cd < 4u;
-    ctxv = ((ctxv << 2) | (cd & 3u)) & ctxmask;
-    vc = valid ? min(vc + 1u, K) : 0u;
+    ctx_step(cd);
     const uint32_t xs = (xh[h] & 0xFFFF0000u) | (xt[h] >> 16), xq = (xh[h] << 16) | (xt[h] & 0xFFFFu);
     const uint32_t bin = min(__umulhi(i * bins, inv), bins - 1u);  // i*binCount/n' (clamp only guards idle lanes)
-    const uint32_t mlen = min(i + 1u, K);
+    const uint32_t mlen = max(vc, 1u);
     const uint32_t mmask = (1u << (2u * mlen)) - 1u;
-    const bool ctx_ok = vc >= mlen && !(B.diag & 16u);
+    const bool ctx_ok = vc >= 1u && vc + xr >= K && !(B.diag & 16u);
     // contexts with m real bases start at (4^m-4)/3 = (0x55555555 & (4^m-1)) - 1
     const uint32_t kidx = ctx_ok ? ((0x55555555u & mmask) - 1u) + (ctxv & mmask) : 0u;
     const uint4 row = SUB_LDS ? lds_sub[kidx * bins + bin] : gsub[(size_t)kidx * bins + bin];
@@ -1009,6 +1022,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // four code bytes (0..
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define FAST_CTX 192u  // context rows per bin: [0,64) three bases, [64,128) two bases (x4), [128,192) one base (x16)
 #define LUT_ROW 12u    // dwords per item in the look-up row: so[0..7], qo[0..1], 2 unused
@@ -1334,7 +1348,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   // L2: WRITE_SIZE 6.43 -> see profiles/r03_final.)
   const bool tail_whole = ((uint32_t)P.L & 7u) == 7u && ((uint32_t)P.L + 7u) / 8u == TI;
   const uint32_t TIp = tail_whole ? TI : TI - 1u;
-  const uint32_t inv_TIp = TIp ? (1u << 20) / TIp + 1u : 0u;  // ceil-reciprocal (i / TIp exact while i * TIp < 2^20)
+  const uint32_t TI16 = TIp >> 1;                             // 16-base items per plain read (the plain16 steps below)
+  const uint32_t inv_TI16 = TI16 ? (1u << 20) / TI16 + 1u : 0u;   // ceil-reciprocal (i / TI16 exact while i * TI16 < 2^20)
 
   // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one
   // stream, 64 per step: lane l of step s does stream item i = 64 s + l = item i % TI of the (i / TI)-th read in step
@@ -1671,7 +1686,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     }
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
     const uint32_t nmain = (dg & 256u) ? 0u : (n_stream + 63u) / 64u;   // (ablations: no general / no plain steps)
-    const uint32_t n_pitems = n_plain * TIp, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
+    // The plain reads' items walk two loops (round 4).  PLAIN16 steps: lane = SIXTEEN bases, items 2c and 2c + 1 of one read
+    // -- one map, one row fetch, one 8-byte window of the 2-bit copy (21 codes = 42 bits), two 16-byte stores for what were
+    // two of each; only WHOLE steps run that way.  What is left -- the 16-base items of the last, partial step, as their two
+    // halves, and the reads' odd last 8-base item (cnt8 = TIp mod 2) -- goes through the 8-base plain steps as one stream,
+    // so that neither loop ends in a step with idle lanes of its own.
+    const uint32_t n_p16 = (dg & 512u) ? 0u : n_plain * TI16;      // (SG_FDIAG 512: no 16-base steps)
+    const uint32_t np16steps = (dg & 128u) ? 0u : n_p16 >> 6, rem16 = n_p16 - (np16steps << 6);
+    const uint32_t cnt8 = (dg & 512u) ? TIp : TIp - 2u * TI16, c8_base = (dg & 512u) ? 0u : 2u * TI16;
+    const uint32_t n_pitems = 2u * rem16 + n_plain * cnt8, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
     // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
@@ -1744,20 +1767,101 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         nfix += (uint32_t)__popcll(fm);
       }
     };
-    // ---- plain steps ----
+    // ---- plain16 steps: whole steps of 16-base items ----
+    if (np16steps) {
+      struct P16 { uint32_t r, c, src, out; uint2 w; };
+      uint32_t TI16_v = TI16, inv_TI16_v = inv_TI16, qual_at = (uint32_t)P.L + 3u;
+      asm volatile("" : "+v"(TI16_v), "+v"(inv_TI16_v), "+v"(qual_at));   // (as scalars they were spilled, see the 8-base loop)
+      auto fetch16 = [&](uint32_t step) -> P16 {
+        P16 st;
+        const uint32_t i = step * 64u + lane;                  // < n_p16: whole steps only, every lane has an item
+        const uint32_t ri = __umul24(i, inv_TI16_v) >> 20;    // i / TI16
+        st.c = i - __umul24(ri, TI16_v);
+        st.r = permp[ri];
+        const uint32_t* row = (const uint32_t*)(meta_rows + st.r * 2);
+        const uint32_t A = row[1];
+        st.src = (A & 0x7FFFFFFFu) + 16u * st.c;
+        st.out = row[3] + 16u * st.c;
+        const uint8_t* copy2 = (PAIRED ? m == 1u : (A >> 31) != 0u) ? B.chains2_rc : B.chains2_fwd;
+        __builtin_memcpy(&st.w, copy2 + (st.src >> 2), 8);
+        return st;
+      };
+      const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
+      const uint32_t lgW = P.lgW;
+      auto run16 = [&](const P16& st) {
+        const uint32_t c8 = 2u * st.c;   // the lane's two 8-base items: c8, c8 + 1
+        // 21 source codes (positions 16c - 5 .. 16c + 15): 42 bits from bit 2 (src mod 4) of the eight bytes on
+        const uint64_t w64 = ((((uint64_t)st.w.y << 32) | st.w.x) >> (2u * (st.src & 3u)));
+        uint32_t cwa = (uint32_t)w64, cwb = (uint32_t)(w64 >> 16);
+        const uint32_t slot = g * G + st.r + B.slot_offset;
+        if (dg & 4u) { cwa = (g * G + st.r) * 2654435761u + c8; cwb = cwa * 40503u + 1u; }  // ablation: no haplotype fetch
+        uint32_t sw[4], qw[4], fixv[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          uint32_t x[8];
+          const uint32_t c = c8 + (uint32_t)hf, cw = hf ? cwb : cwa;
+          if (dg & 8u) {  // ablation: no Philox
+#pragma unroll
+            for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
+          } else {
+            philox_base(slot, 2u * c, 0, c3b, B.k0, B.k1, x);
+            philox_base(slot, 2u * c + 1u, 0, c3b, B.k0, B.k1, x + 4);
+          }
+          const uint4* lrow = (const uint4*)(lut + c * LUT_ROW);
+          const uint4 r0 = lrow[0], r1 = lrow[1], r2 = lrow[2];
+          const uint32_t so[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          uint32_t s2[2], q2[2], acc;
+          sample8(code4, lgW, cw, x, so, r2.x, r2.y, s2, q2, acc);
+          sw[2 * hf] = s2[0]; sw[2 * hf + 1] = s2[1];
+          qw[2 * hf] = q2[0]; qw[2 * hf + 1] = q2[1];
+          fixv[hf] = (dg & 16u) ? 0u : (acc >> 17) & 0xFFu;
+        }
+        const uint32_t so_ = (dg & 1u) ? 0xFFFFFFFFu : st.out;
+        const uint32_t qo_ = (dg & 1u) ? 0xFFFFFFFFu : st.out + qual_at;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{sw[0], sw[1], sw[2], sw[3]}, out_rsrc, so_, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, out_rsrc, qo_, 0, 0);
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          const uint32_t fix = fixv[hf];
+          const unsigned long long fm = __ballot(fix != 0u);
+          if (fm) {
+            if (nfix + 64u > FIX_CAP) flush_fix();
+            if (fix != 0u)
+              fix_list[nfix + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = make_uint2(st.r | (fix << 6) | ((c8 + (uint32_t)hf) << 17), hf ? cwb : cwa);
+            nfix += (uint32_t)__popcll(fm);
+          }
+        }
+      };
+      P16 cur = fetch16(0);
+      // (two dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
+      for (uint32_t step = 0; step < np16steps; step++) {
+        const P16 nxt = fetch16(min(step + 1u, np16steps - 1u));
+        run16(cur);
+        cur = nxt;
+      }
+    }
+    // ---- plain steps (8-base items): the halves of the 16-base items the whole steps above left over, then the reads' own
+    // odd last item ----
     if (npsteps) {
       struct PStage { uint32_t r, c, src, out; bool ok; uint2 w; };
-      // (three wave-uniform values of every step held in vector registers: as scalars they were spilled and came back
+      // (wave-uniform values of every step held in vector registers: as scalars they were spilled and came back
       // through a v_readlane_b32 in every step)
-      uint32_t TIp_v = TIp, inv_TIp_v = inv_TIp, qual_at = (uint32_t)P.L + 3u;
-      asm volatile("" : "+v"(TIp_v), "+v"(inv_TIp_v), "+v"(qual_at));
+      uint32_t qual_at = (uint32_t)P.L + 3u, n_half = 2u * rem16, i16_base = np16steps << 6;
+      asm volatile("" : "+v"(qual_at), "+v"(n_half), "+v"(i16_base));
+      const uint32_t inv_cnt8 = cnt8 ? (1u << 20) / cnt8 + 1u : 0u;
       auto fetch_plain = [&](uint32_t step) -> PStage {
         PStage st;
         const uint32_t i_raw = step * 64u + lane;
         st.ok = i_raw < n_pitems;
         const uint32_t i = min(i_raw, n_pitems - 1u);     // idle lanes redo the stream's last item, their stores are dropped
-        const uint32_t ri = __umul24(i, inv_TIp_v) >> 20;  // i / TIp
-        st.c = i - __umul24(ri, TIp_v);
+        const bool half = i < n_half;                     // a half of a left-over 16-base item / a read's own 8-base item
+        const uint32_t q = half ? i16_base + (i >> 1) : i - n_half;
+        const uint32_t d = half ? TI16 : cnt8;
+        const uint32_t ri = __umul24(q, half ? inv_TI16 : inv_cnt8) >> 20;  // q / d
+        const uint32_t rem = q - __umul24(ri, d);
+        st.c = half ? 2u * rem + (i & 1u) : c8_base + rem;
         st.r = permp[ri];
         const uint32_t* row = (const uint32_t*)(meta_rows + st.r * 2);
         const uint32_t A = row[1];
@@ -1983,7 +2087,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_slow_kernel(DevProfile P, D
 }
 
 // ------------------------------------------------------------------------------------------------
-// haplotype encoding: ASCII -> base code, in place (A0 C1 T2 G3, 'N' = 4, anything else = 5)
+// haplotype encoding: ASCII -> base code, in place (A0 C1 T2 G3, 'N' = 4, 'X' = 6, anything else = 5)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t encode4(uint32_t w) {
   uint32_t o = 0;
@@ -1991,7 +2095,7 @@ __device__ __forceinline__ uint32_t encode4(uint32_t w) {
   for (int i = 0; i < 4; i++) {
     const uint32_t b = (w >> (8 * i)) & 0xFFu;
     const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
-    const uint32_t v = acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : 5u);
+    const uint32_t v = acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : (b == 'X' ? 6u : 5u));
     o |= v << (8 * i);
   }
   return o;

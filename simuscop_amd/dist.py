@@ -10,7 +10,56 @@ with it, occasionally, a truncated read count.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
+
+
+def pg_timeout_s() -> int:
+    """Seconds a collective may wait for its peers before the group gives up (SIMUSCOP_PG_TIMEOUT_S, default 120): a rank
+    that died must take the others out, not leave them in a collective until the launcher's own limit."""
+    return int(os.environ.get("SIMUSCOP_PG_TIMEOUT_S", "120"))
+
+
+def init_process_group(backend: str, local_rank: int, world: int, force: bool = False) -> bool:
+    """The one place a process group is made (bench.py, bench_c3.py, simuscop_amd.run).  `backend` "nccl" is RCCL on ROCm
+    (device tensors, communicator bound to cuda:`local_rank`), anything else (gloo) is for CPU rehearsals.  With one rank
+    no group is needed; `force` (or SIMUSCOP_FORCE_PG=1) makes one anyway so that the collectives of the sharded path run
+    through the real transport on a single leased GPU (tests/test_gpu_nccl_world1.py).  Every group has a timeout.
+    Returns whether a group exists."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    force = force or os.environ.get("SIMUSCOP_FORCE_PG") == "1"
+    if world <= 1 and not force:
+        return False
+    if dist.is_initialized():
+        return True
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = dict(timeout=datetime.timedelta(seconds=pg_timeout_s()))
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ or "MASTER_PORT" not in os.environ:
+        # a single process without a launcher: a one-rank group on a free local port
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        kw.update(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
+    else:
+        dist.init_process_group(backend, **kw)
+    return True
+
+
+# collectives this process ran through torch.distributed, by name (bench.py reports them: evidence that the transport ran)
+COLLECTIVES = {"all_gather": 0, "all_reduce": 0}
+
+
+def group_active() -> bool:
+    """True when collectives should run: a process group exists (also a one-rank group made with `force`)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def apportion(reads: int, chr_wl: Sequence[float]) -> List[int]:
@@ -35,11 +84,12 @@ def balance_reads(my_wl: float, my_target_len: int, coverage: int, read_length: 
     import torch
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if group_active():   # (a one-rank group too: the all_gather then runs through the transport alone)
         rank, world = dist.get_rank(), dist.get_world_size()
         t = torch.tensor([my_wl, float(my_target_len)], dtype=torch.float64, device=device)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
+        COLLECTIVES["all_gather"] += 1
         wls = [float(p[0]) for p in parts]
         total_len = int(sum(int(p[1]) for p in parts))
     else:
@@ -64,11 +114,12 @@ def make_exchange(device=None):
 
     def _exchange(_user, values, n):
         try:
-            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            if not group_active():
                 return 0
             arr = np.ctypeslib.as_array(values, shape=(n,))
             t = torch.from_numpy(arr.copy()).to(device) if device is not None else torch.from_numpy(arr.copy())
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            COLLECTIVES["all_reduce"] += 1
             arr[:] = t.cpu().numpy()
             return 0
         except Exception:   # a Python exception must not unwind through the C++ caller

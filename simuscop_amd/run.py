@@ -30,6 +30,8 @@ def main(argv=None):
     ap.add_argument("--no-write", action="store_true", help="keep results on the devices (throughput runs)")
     ap.add_argument("--merge", action="store_true", help="rank 0 concatenates the part files per output file")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="make a process group even for one rank (rehearsal of the RCCL path on a single GPU)")
     ap.add_argument("--shard-contigs", action="store_true",
                     help="ranks own whole chromosomes: each ingests, scans and samples only its own; the per-chromosome "
                          "weighted lengths are exchanged with one all-reduce per population")
@@ -46,21 +48,16 @@ def main(argv=None):
         raise SystemExit("simuscop_amd.run needs MI355X devices: the engine has no CPU path")
     if os.environ.get("SIMUSCOP_SAME_DEVICE"):   # rehearsal on a 1-GPU box (gloo backend only)
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+    from simuscop_amd import dist as sdist
+    torch.cuda.set_device(local_rank)
+    pg = sdist.init_process_group(args.backend, local_rank, world, force=args.force_process_group)
 
     opts = dict(device=local_rank, quiet=0 if rank == 0 else 1, shard_rank=rank, shard_world=world,
                 write_files=0 if args.no_write else 1)
     if args.seed is not None:
         opts["seed"] = args.seed
     exchange = None
-    if args.shard_contigs and world > 1:
-        from simuscop_amd import dist as sdist
+    if args.shard_contigs and pg:
         exchange = sdist.make_exchange("cuda" if args.backend == "nccl" else None)
         opts["shard_contigs"] = 1
         opts["exchange"] = exchange
@@ -69,7 +66,7 @@ def main(argv=None):
     dt = time.time() - t0
     mine = {"rank": rank, "reads": int(st.reads), "fragments": int(st.fragments), "bytes": int(st.fastq_bytes),
             "seconds": dt, "t_sample": st.t_sample}
-    if world > 1:
+    if pg:
         allv = [None] * world
         dist.all_gather_object(allv, mine)
         dist.barrier()
@@ -97,7 +94,7 @@ def main(argv=None):
                         with open(part, "rb") as src:
                             shutil.copyfileobj(src, dst, 1 << 24)
                         os.remove(part)
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
 
 

@@ -64,6 +64,22 @@ ABUNDANCE_VARIANTS = {   # rows of the abundance file of the four-population mix
 }
 
 
+def literal_x(seq, other=False):
+    """`seq` with 400 short runs of X / x (and a few R) put in; other=True: the same places hold R / r instead of X / x
+    (what --strict-bases makes of an X: an unknown base like any other)."""
+    import random
+    rng = random.Random(5)
+    out = bytearray(seq)
+    for _ in range(400):
+        p = rng.randrange(10, len(out) - 10)
+        n = rng.choice([1, 1, 2, 2, 3, 5])
+        ch = rng.choice([b"X", b"X", b"x", b"R"])
+        if other:
+            ch = {b"X": b"R", b"x": b"r"}.get(ch, ch)
+        out[p:p + n] = ch * n
+    return bytes(out)
+
+
 def _fasta_variants():
     """FASTA files fastahack indexes (Fasta.cpp:45-85) in shapes the ingest kernels have to cope with."""
     from simuscop_amd import synth
@@ -74,6 +90,11 @@ def _fasta_variants():
         return b"".join(seq[i:i + w] + eol for i in range(0, len(seq), w))
 
     return {
+        # a literal X walks the reference's k-mer trie as the place holder of the short contexts (Profile.cpp:94-101): runs of
+        # one to five, lower case too, next to other non-ACGT characters
+        "fasta_literal_x": [b">chr1\n", wrap(literal_x(a), 60), b">chr2\n", wrap(b, 60)],
+        # a name met again: listed twice, both resolved to the FIRST sequence (Fasta.cpp:67,84-97,198)
+        "fasta_repeated_name": [b">chr1\n", wrap(a, 60), b">chr2\n", wrap(b, 60), b">chr1\n", wrap(a[:12000][::-1], 60)],
         "fasta_lf": [b">chr1\n", wrap(a, 60), b">chr2\n", wrap(b, 60)],
         "fasta_crlf": [b">chr1\r\n", wrap(a, 60, b"\r\n"), b">chr2\r\n", wrap(b, 60, b"\r\n")],
         "fasta_header_with_description": [b">chr1 some description here\n", wrap(a, 60), b">chr2 other\n", wrap(b, 60)],
@@ -87,7 +108,7 @@ def _fasta_variants():
 
 
 _FASTA_NAMES = ["fasta_blank_line_between_contigs", "fasta_crlf", "fasta_lf", "fasta_empty_contig", "fasta_header_with_description", "fasta_lower_case",
-                "fasta_no_final_newline", "fasta_one_line_per_contig", "fasta_trailing_space"]
+                "fasta_no_final_newline", "fasta_one_line_per_contig", "fasta_trailing_space", "fasta_literal_x", "fasta_repeated_name"]
 _VARIATION_NAMES = sorted(_variation_variants(["i\tp\tc\t1\tA\thomo"]))
 NAMES = sorted(WGS_VARIANTS) + sorted(_bed_variants(["chr20\t1\t2"] * 6)) + _VARIATION_NAMES + ["snp_on_absent_chromosome"] + sorted(ABUNDANCE_VARIANTS) + _FASTA_NAMES
 
@@ -139,9 +160,8 @@ def build(name, workdir):
     return cfg
 
 
-# The one place where the GPU path deliberately does NOT follow the oracle (and the reference): a FASTA with CRLF line
-# ends.  fastahack keeps the carriage returns -- in the contig names ("@fa#1\r#69#1/1") and, one per line, in the
-# sequence, where they count as unknown bases (Fasta.cpp:150-199: line_blen includes them) -- so nearly every window
-# holds a non-ACGT byte and the run degenerates.  The oracle restates that (it is pinned on the binary); the product
-# reads such a file like its LF twin (test_gpu_edge_inputs.py checks exactly that).
-GPU_NAMES = [n for n in NAMES if n != "fasta_crlf"]
+# Every name runs through the GPU path too.  Three reference quirks were the product's own reading in round 3 (CR LF line
+# ends read like LF, a literal X an unknown base, a repeated contig name keeping its last sequence); the default is now the
+# reference's behaviour -- "fasta_crlf", "fasta_literal_x", "fasta_repeated_name" are byte-parity cases like the others --
+# and the old readings sit behind --crlf-as-lf / --strict-bases / --unique-contigs (tests/test_gpu_edge_inputs.py).
+GPU_NAMES = list(NAMES)

@@ -20,7 +20,10 @@
 enum Op { OP_ADD, OP_BITOP3, OP_MAD_U64_U32, OP_MUL_LO, OP_MUL_HI, OP_MUL_U24, OP_MAD_U24, OP_BFE, OP_CNDMASK, OP_PERM,
           OP_LSHL_OR, OP_ADD_LSHL, OP_CMP_ADDC, OP_ALIGNBIT, OP_LDS_B32, OP_LDS_B64, OP_LDS_B128, OP_PHILOX,
           OP_AND, OP_XOR, OP_LSHLREV, OP_LSHRREV, OP_LSHR_CONST, OP_SUB, OP_MAX, OP_ADD3, OP_AND_OR, OP_OR3, OP_CMP_E32, OP_CMP_E64,
-          OP_CNDMASK_E64, OP_CNDMASK_SET, OP_MOV, OP_FMA, OP_ADD_SDWA, OP_XAD, OP_LSHL_ADD, OP_SAD, OP_MED3, OP_MIX_ADD_BFE, OP_MIX_3ADD_BFE, OP_ADD_2CHAINS, OP_AND_LSHR_SUB, OP_COUNT };
+          OP_CNDMASK_E64, OP_CNDMASK_SET, OP_MOV, OP_FMA, OP_ADD_SDWA, OP_XAD, OP_LSHL_ADD, OP_SAD, OP_MED3, OP_MIX_ADD_BFE, OP_MIX_3ADD_BFE, OP_ADD_2CHAINS, OP_AND_LSHR_SUB,
+          OP_PK_SUB_U16, OP_PK_ADD_U16, OP_PK_MIN_U16, OP_PK_MAX_I16, OP_PK_ASHR_I16, OP_PK_LSHR_B16, OP_PK_LSHL_B16, OP_PK_MUL_LO_U16, OP_PK_MAD_U16,
+          OP_SUB_SDWA2, OP_AND_SDWA, OP_SUB_U16, OP_ADD_DPP_ROW_SHR, OP_MOV_DPP_ROW_SHR, OP_ADD_DPP_QUAD, OP_DS_BPERMUTE, OP_DS_SWIZZLE,
+          OP_LDS_U16_D16, OP_LDS_U16_D16_PAIR, OP_LDS_U8, OP_LDS_READ2_B32, OP_DOT4_U8, OP_MIX_PK_PERM_BITOP, OP_COUNT };
 static const char* kNames[OP_COUNT] = {"v_add_u32", "v_bitop3_b32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24",
                                        "v_mad_u32_u24", "v_bfe_u32", "v_cndmask_b32 (vcc never written)", "v_perm_b32", "v_lshl_or_b32", "v_add_lshl_u32",
                                        "v_cmp_gt_u32 + v_addc", "v_alignbit_b32", "ds_read_b32 (random bank)", "ds_read_b64 (random bank)",
@@ -30,7 +33,14 @@ static const char* kNames[OP_COUNT] = {"v_add_u32", "v_bitop3_b32", "v_mad_u64_u
                                        "v_cmp_gt_u32_e64 (sgpr pair)", "v_cndmask_b32_e64 (sgpr pair mask)", "v_cndmask_b32 (vcc written once before the loop)",
                                        "v_mov_b32", "v_fma_f32", "v_add_u32_sdwa (WORD_1 operand)", "v_xad_u32", "v_lshl_add_u32", "v_sad_u32", "v_med3_u32",
                                        "mix: v_add_u32, v_bfe_u32 alternating", "mix: 3 x v_add_u32, 1 x v_bfe_u32", "v_add_u32, 2 dependent chains per wave",
-                                       "mix: v_and_b32, v_lshrrev_b32, v_sub_u32 (full-rate only)"};
+                                       "mix: v_and_b32, v_lshrrev_b32, v_sub_u32 (full-rate only)",
+                                       "v_pk_sub_u16", "v_pk_add_u16", "v_pk_min_u16", "v_pk_max_i16", "v_pk_ashrrev_i16 (vgpr amount)", "v_pk_lshrrev_b16 (vgpr amount)",
+                                       "v_pk_lshlrev_b16 (vgpr amount)", "v_pk_mul_lo_u16", "v_pk_mad_u16",
+                                       "v_sub_u32_sdwa (WORD_0 - WORD_0 of two registers)", "v_and_b32_sdwa (WORD_1 operand)", "v_sub_u16",
+                                       "v_add_u32_dpp row_shr:1", "v_mov_b32_dpp row_shr:1", "v_add_u32_dpp quad_perm:[1,0,3,2]", "ds_bpermute_b32", "ds_swizzle_b32 (swap 1)",
+                                       "ds_read_u16_d16 (random bank)", "ds_read_u16_d16 + ds_read_u16_d16_hi into one register (random banks; per pair)",
+                                       "ds_read_u8 (random bank)", "ds_read2_b32 (two random banks)", "v_dot4_u32_u8",
+                                       "mix: v_pk_sub_u16, v_perm_b32, v_bitop3_b32 alternating"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void bench(uint32_t* out, uint64_t* clk, int trips, uint32_t seed) {
@@ -95,6 +105,55 @@ __global__ __launch_bounds__(1024) void bench(uint32_t* out, uint64_t* clk, int 
           else if (c % 3 == 1) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(v[c]));
           else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
         }
+
+        if (OP == OP_PK_SUB_U16) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_ADD_U16) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_MIN_U16) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_MAX_I16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_ASHR_I16) asm volatile("v_pk_ashrrev_i16 %0, %1, %0" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_LSHR_B16) asm volatile("v_pk_lshrrev_b16 %0, %1, %0" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_LSHL_B16) asm volatile("v_pk_lshlrev_b16 %0, %1, %0" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_MUL_LO_U16) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_PK_MAD_U16) asm volatile("v_pk_mad_u16 %0, %0, %1, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_SUB_SDWA2) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_AND_SDWA) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_SUB_U16) asm volatile("v_sub_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_ADD_DPP_ROW_SHR) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_MOV_DPP_ROW_SHR) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_ADD_DPP_QUAD) asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_DS_BPERMUTE) { uint32_t r; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(w[c]), "v"(v[c])); w[c] ^= r; v[c] += 0x9E3779B9u; }
+        if (OP == OP_DS_SWIZZLE) { uint32_t r; asm volatile("ds_swizzle_b32 %0, %1 offset:swizzle(SWAP,1)" : "=v"(r) : "v"(v[c])); w[c] ^= r; v[c] += 0x9E3779B9u; }
+        if (OP == OP_LDS_U16_D16) {
+          uint32_t a = (v[c] & 16383u) << 1, r = w[c];
+          asm volatile("ds_read_u16_d16 %0, %1" : "+v"(r) : "v"(a));
+          w[c] ^= r;
+          v[c] += 0x9E3779B9u;
+        }
+        if (OP == OP_LDS_U16_D16_PAIR) {
+          uint32_t a = (v[c] & 16383u) << 1, b = (w[c] & 16383u) << 1, r = 0;
+          asm volatile("ds_read_u16_d16 %0, %1\n ds_read_u16_d16_hi %0, %2" : "+v"(r) : "v"(a), "v"(b));
+          w[c] ^= r;
+          v[c] += 0x9E3779B9u;
+        }
+        if (OP == OP_LDS_U8) {
+          uint32_t a = (v[c] & 32767u), r;
+          asm volatile("ds_read_u8 %0, %1" : "=v"(r) : "v"(a));
+          w[c] ^= r;
+          v[c] += 0x9E3779B9u;
+        }
+        if (OP == OP_LDS_READ2_B32) {
+          uint32_t a = (v[c] & 4095u) << 2;
+          uint64_t r;
+          asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:37" : "=v"(r) : "v"(a));
+          w[c] ^= (uint32_t)r ^ (uint32_t)(r >> 32);
+          v[c] += 0x9E3779B9u;
+        }
+        if (OP == OP_DOT4_U8) asm volatile("v_dot4_u32_u8 %0, %0, %1, %1" : "+v"(v[c]) : "v"(w[c]));
+        if (OP == OP_MIX_PK_PERM_BITOP) {
+          if (c % 3 == 0) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(v[c]) : "v"(w[c]));
+          else if (c % 3 == 1) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(v[c]) : "v"(w[c]));
+          else asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(v[c]) : "v"(w[c]));
+        }
         if (OP == OP_LDS_B32) {
           uint32_t a = (v[c] & 8191u) << 2, r;
           asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(a));
@@ -141,7 +200,7 @@ __global__ __launch_bounds__(1024) void bench(uint32_t* out, uint64_t* clk, int 
 
 template <int OP>
 static void run(uint32_t* d_out, uint64_t* d_clk, int cus) {
-  const int trips = OP == OP_PHILOX ? 2000 : (OP >= OP_LDS_B32 ? 300 : 1000);
+  const int trips = OP == OP_PHILOX ? 2000 : (((OP >= OP_LDS_B32 && OP <= OP_PHILOX) || (OP >= OP_DS_BPERMUTE && OP <= OP_LDS_READ2_B32)) ? 300 : 1000);
   for (int wps : {1, 4, 8}) {  // waves per SIMD; 8 needs two 1024-thread workgroups per CU
     const int threads = wps == 1 ? 256 : 1024, blocks = cus * (wps == 8 ? 2 : 1);
     hipEvent_t a, b;
@@ -174,7 +233,7 @@ static void run(uint32_t* d_out, uint64_t* d_clk, int cus) {
       if (ms < base) base = ms;
     }
     (void)cyc;
-    const double per_wave = OP == OP_PHILOX ? (double)trips * 2 : (double)trips * UNROLL * CHAINS * (OP == OP_CMP_ADDC ? 2 : 1);
+    const double per_wave = OP == OP_PHILOX ? (double)trips * 2 : (double)trips * UNROLL * CHAINS * (OP == OP_CMP_ADDC ? 2 : 1) /* a d16 pair counts once */;
     const double insts = per_wave * wps;
     const double ns = (double)(best - base) * 1e6 / insts;
     printf("%-50s %d waves/SIMD: %7.3f ns = %6.2f cycles per wave-%s per SIMD  (in-kernel clock %.0f MHz, launch %.3f ms)\n", kNames[OP], wps,
@@ -183,7 +242,8 @@ static void run(uint32_t* d_out, uint64_t* d_clk, int cus) {
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool only_new = argc > 1 && argv[1][0] == 'n';  // `valu_microbench new`: the rows added in round 4 only
   int dev = 0, cus = 256;
   hipGetDevice(&dev);
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -192,6 +252,7 @@ int main() {
   hipMalloc(&d_out, (size_t)cus * 2 * 1024 * 4);
   hipMalloc(&d_clk, (size_t)cus * 2 * 16);
   printf("CUs %d; one workgroup per CU (two at 8 waves/SIMD); %d independent chains per lane\n", cus, CHAINS);
+  if (!only_new) {
   run<OP_ADD>(d_out, d_clk, cus);
   run<OP_BITOP3>(d_out, d_clk, cus);
   run<OP_MAD_U64_U32>(d_out, d_clk, cus);
@@ -235,5 +296,29 @@ int main() {
   run<OP_MIX_3ADD_BFE>(d_out, d_clk, cus);
   run<OP_ADD_2CHAINS>(d_out, d_clk, cus);
   run<OP_AND_LSHR_SUB>(d_out, d_clk, cus);
+  }
+  run<OP_PK_SUB_U16>(d_out, d_clk, cus);
+  run<OP_PK_ADD_U16>(d_out, d_clk, cus);
+  run<OP_PK_MIN_U16>(d_out, d_clk, cus);
+  run<OP_PK_MAX_I16>(d_out, d_clk, cus);
+  run<OP_PK_ASHR_I16>(d_out, d_clk, cus);
+  run<OP_PK_LSHR_B16>(d_out, d_clk, cus);
+  run<OP_PK_LSHL_B16>(d_out, d_clk, cus);
+  run<OP_PK_MUL_LO_U16>(d_out, d_clk, cus);
+  run<OP_PK_MAD_U16>(d_out, d_clk, cus);
+  run<OP_SUB_SDWA2>(d_out, d_clk, cus);
+  run<OP_AND_SDWA>(d_out, d_clk, cus);
+  run<OP_SUB_U16>(d_out, d_clk, cus);
+  run<OP_ADD_DPP_ROW_SHR>(d_out, d_clk, cus);
+  run<OP_MOV_DPP_ROW_SHR>(d_out, d_clk, cus);
+  run<OP_ADD_DPP_QUAD>(d_out, d_clk, cus);
+  run<OP_DS_BPERMUTE>(d_out, d_clk, cus);
+  run<OP_DS_SWIZZLE>(d_out, d_clk, cus);
+  run<OP_LDS_U16_D16>(d_out, d_clk, cus);
+  run<OP_LDS_U16_D16_PAIR>(d_out, d_clk, cus);
+  run<OP_LDS_U8>(d_out, d_clk, cus);
+  run<OP_LDS_READ2_B32>(d_out, d_clk, cus);
+  run<OP_DOT4_U8>(d_out, d_clk, cus);
+  run<OP_MIX_PK_PERM_BITOP>(d_out, d_clk, cus);
   return 0;
 }
