@@ -317,23 +317,53 @@ int sg_kernel_times(sg_ctx* ctx, float ms[SG_K_COUNT]);
  * their queue overflowed so that the whole batch was emitted again by the generic kernel.  Results
  * are identical either way (Profile::predict, Profile.cpp:1520-1650 has one code path).          */
 int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
-/* ---- profile training, counting half ---------------------------------------------
- * What Profile::processRead (lib/profile/Profile.cpp:228-510) adds to its count matrices for lines of `samtools view`
- * text (the reference reads them through popen, Profile.cpp:1448-1462): the filters of :262-288, the CIGAR walk with its
- * insertion / deletion length counts (:294-388; only a single nM reaches the counters), subsDist1 / subsDist2 / kmersDist
- * (:405-441), iSizeDist (:443-450), qualityDist (:452-480).  The reference bases come from the contigs committed with
- * sg_reference_commit (upper-cased as Genome.cpp:529); `contig_keys` names them in that order, chr / chrom prefix
- * stripped.  Not included: Profile::countGC (:512-703, sequential over the file; it also gates which reads count) and
- * known variants (the VCF side); reads overhanging their contig's end are skipped and counted in skipped_overhang.
- * Arrays are the caller's: subs1 / subs2 [kmer_count][bins][4], kmers [bins][kmer_count], quality [16][bins][94],
- * isize [n_isize].  Bases must be a permutation of ACGT, kmer 1..6.                                                  */
+/* ---- profile training: what Profile::train gathers from the reads (lib/profile/Profile.cpp:1442-1484) ----
+ * Lines of `samtools view` text (the reference reads them through popen, Profile.cpp:1448-1462) go through
+ * Profile::processRead (:228-510) in file order, chunk by chunk: the filters of :262-279, Profile::countGC (:512-703: the
+ * window whose reads are being counted; it turns reads away and opens windows), the CIGAR walk with its insertion /
+ * deletion length counts (:290-382; events the VCF knows are not counted, only a single nM reaches the matrices),
+ * subsDist1 / subsDist2 / kmersDist (:399-442), iSizeDist (:444-451), qualityDist (:453-481).  The reference bases come from
+ * the contigs committed with sg_reference_commit (upper-cased, Genome.cpp:529); `contig_keys` names them in that order as the
+ * FASTA index does (first token, chr / chrom prefix stripped, Fasta.cpp:58-69).
+ *   sg_train_begin   tables zeroed, targets and known variants staged (refSequence / altSequence of Genome.cpp:466-475)
+ *   sg_train_feed    one chunk of WHOLE lines, in file order; state is carried from chunk to chunk
+ *   sg_train_finish  the count matrices; the (GC content, read count) pairs countGC pushed, in its order (gcs, readCounts)
+ * Where the reference's behaviour is undefined the line is skipped and counted: reads hanging over their contig's end
+ * (skipped_overhang).  Arrays are the caller's: subs1 / subs2 [kmer_count][bins][4], kmers [bins][kmer_count], quality
+ * [16][bins][94], isize [n_isize], ins_len / del_len [n_indel_len].  Bases must be a permutation of ACGT, kmer 1..6.       */
+typedef struct sg_train_setup {
+  const char* const* contig_keys;
+  uint32_t n_contigs;
+  const char* bases;
+  int32_t kmer, bins;
+  uint32_t n_isize;        /* columns of iSizeDist kept (the reference grows its row; larger TLENs: isize_overflow) */
+  uint32_t n_indel_len;    /* columns of insFreqs / delFreqs kept (longer events: indel_len_overflow) */
+  int32_t count_gc;        /* 1: Profile::countGC gates and counts as the reference does; 0: every read through the filters counts */
+  uint32_t window;         /* Segment::fragSize (1000) */
+  /* exome: inTargets[chr] after loadTargets + divideTargets (Genome.cpp:238-299, 684-739), in that order; the rows of contig c
+   * are [target_first[c], target_first[c + 1]); spos / epos as the reference holds them.  NULL / no rows: whole genome. */
+  const uint64_t* target_first;
+  const int64_t* target_spos;
+  const int64_t* target_epos;
+  /* known variants of the sample (lib/vcfparser/vcfparser.cpp:26-106), in file order; positions as the parser stores them */
+  uint64_t n_snv;  const uint32_t* snv_contig;  const int64_t* snv_pos;  const char* snv_alt;  const uint8_t* snv_homo;
+  uint64_t n_ins;  const uint32_t* ins_contig;  const int64_t* ins_pos;  const int32_t* ins_len;
+  uint64_t n_del;  const uint32_t* del_contig;  const int64_t* del_pos;  const int32_t* del_len;
+} sg_train_setup;
 typedef struct sg_train_counts {
-  uint64_t *subs1, *subs2, *kmers, *quality, *isize;
-  uint64_t ins_len[256], del_len[256];
-  uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, skipped_overhang;
+  uint64_t *subs1, *subs2, *kmers, *quality, *isize, *ins_len, *del_len;
+  uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, indel_len_overflow, skipped_overhang,
+      gc_rejected, gc_windows;
 } sg_train_counts;
+int sg_train_begin(sg_ctx* ctx, const sg_train_setup* setup);
+int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes);
+/* gc / rc: room for `gc_cap` pairs (NULL: none wanted); *n_gc = how many there are (SG_ERR_OVERFLOW when gc_cap is too small;
+ * call again).  The session ends with a successful call or with sg_train_end. */
+int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, uint64_t gc_cap, uint64_t* n_gc);
+void sg_train_end(sg_ctx* ctx);
+/* One call for a text that fits memory: begin (no targets, no variants, count_gc = 0) + feed + finish. */
 int sg_train_count(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes, const char* const* contig_keys, uint32_t n_contigs,
-                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, sg_train_counts* out);
+                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, uint32_t n_indel_len, sg_train_counts* out);
 
 /* Which emit kernel the loaded profile gets (after sg_load_profile): 0 generic (tables that do not fit
  * LDS, k-mer sizes other than 3), 1 straight-line kernel (table image in LDS). */

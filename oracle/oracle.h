@@ -61,16 +61,22 @@ int orc_profile_indel_gaps(const orc_profile*, uint64_t ab[2], uint64_t* gaps, i
 int orc_predict_philox(const orc_profile*, const char* ref, int n, int is_read1, uint64_t seed,
                        uint32_t batch_id, uint32_t pair_slot, char* out_bases, char* out_quals);
 
-// ---- profile training, counting half (Profile::processRead, Profile.cpp:228-510): see train_oracle.cpp ----
+// ---- profile training (Profile::train, Profile.cpp:1442-1484): see train_oracle.cpp ----
 // Caller-allocated count arrays: subs1/subs2 [kmer_count][bins][N], kmers [bins][kmer_count], quality [N*N][bins][94],
-// isize [n_isize].  PARITY UNPINNED (no samtools / BAM in this image): restated from the source, not run against it.
+// isize [n_isize], ins_len / del_len [n_indel_len] (same layout as sg_train_counts).  PARITY UNPINNED for the counting
+// (no samtools / BAM in this image): restated from the source, not run against it.
 typedef struct orc_train_counts {
-  uint64_t *subs1, *subs2, *kmers, *quality, *isize;
-  uint64_t ins_len[256], del_len[256];
-  uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, skipped_overhang;
+  uint64_t *subs1, *subs2, *kmers, *quality, *isize, *ins_len, *del_len;
+  uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, indel_len_overflow, skipped_overhang,
+      gc_rejected, gc_windows;
 } orc_train_counts;
 int orc_train_count(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* bases, int kmer, int bins,
-                    uint32_t n_isize, orc_train_counts* out);
+                    uint32_t n_isize, uint32_t n_indel_len, orc_train_counts* out);
+int orc_train(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* vcf_path, const char* bed_path,
+              const char* bases, int kmer, int bins, uint32_t n_isize, uint32_t n_indel_len, orc_train_counts* out,
+              double* gc, double* rc, uint64_t cap, uint64_t* n_gc);
+int orc_train_profile(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* vcf_path, const char* bed_path,
+                      const char* bases, int kmer, int bins, const char* out_path, const char* bam_label, const char* stamp);
 
 // Philox known-answer helpers (orc_base_rounds: the round count of the per-base draws, philox.h kBaseRounds)
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -28,6 +28,7 @@ ENGINE_SYMBOLS = [
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
     "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free", "sg_train_count",
+    "sg_train_begin", "sg_train_feed", "sg_train_finish", "sg_train_end",
     "sg_release_cached_memory",
 ]
 
@@ -36,9 +37,21 @@ class SgTrainCounts(C.Structure):
     """sg_train_counts / orc_train_counts (same layout): caller-allocated count arrays + scalar counters."""
     _fields_ = [("subs1", C.POINTER(C.c_uint64)), ("subs2", C.POINTER(C.c_uint64)), ("kmers", C.POINTER(C.c_uint64)),
                 ("quality", C.POINTER(C.c_uint64)), ("isize", C.POINTER(C.c_uint64)),
-                ("ins_len", C.c_uint64 * 256), ("del_len", C.c_uint64 * 256),
+                ("ins_len", C.POINTER(C.c_uint64)), ("del_len", C.POINTER(C.c_uint64)),
                 ("lines", C.c_uint64), ("reads_counted", C.c_uint64), ("cigar_chars", C.c_uint64), ("insert_events", C.c_uint64),
-                ("delete_events", C.c_uint64), ("isize_overflow", C.c_uint64), ("skipped_overhang", C.c_uint64)]
+                ("delete_events", C.c_uint64), ("isize_overflow", C.c_uint64), ("indel_len_overflow", C.c_uint64),
+                ("skipped_overhang", C.c_uint64), ("gc_rejected", C.c_uint64), ("gc_windows", C.c_uint64)]
+
+
+class SgTrainSetup(C.Structure):
+    """sg_train_setup (include/simuscop_amd.h)"""
+    _fields_ = [("contig_keys", C.POINTER(C.c_char_p)), ("n_contigs", C.c_uint32), ("bases", C.c_char_p), ("kmer", C.c_int32),
+                ("bins", C.c_int32), ("n_isize", C.c_uint32), ("n_indel_len", C.c_uint32), ("count_gc", C.c_int32), ("window", C.c_uint32),
+                ("target_first", C.POINTER(C.c_uint64)), ("target_spos", C.POINTER(C.c_int64)), ("target_epos", C.POINTER(C.c_int64)),
+                ("n_snv", C.c_uint64), ("snv_contig", C.POINTER(C.c_uint32)), ("snv_pos", C.POINTER(C.c_int64)), ("snv_alt", C.c_char_p),
+                ("snv_homo", C.POINTER(C.c_uint8)),
+                ("n_ins", C.c_uint64), ("ins_contig", C.POINTER(C.c_uint32)), ("ins_pos", C.POINTER(C.c_int64)), ("ins_len", C.POINTER(C.c_int32)),
+                ("n_del", C.c_uint64), ("del_contig", C.POINTER(C.c_uint32)), ("del_pos", C.POINTER(C.c_int64)), ("del_len", C.POINTER(C.c_int32))]
 
 
 class SgProfileCdf(C.Structure):
@@ -134,7 +147,12 @@ def load_engine():
     lib.sg_reference_scan.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.sg_reference_commit.argtypes = [vp, C.POINTER(SgContig), C.c_uint32]
     lib.sg_train_count.argtypes = [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_int32, C.c_int32,
-                                   C.c_uint32, C.POINTER(SgTrainCounts)]
+                                   C.c_uint32, C.c_uint32, C.POINTER(SgTrainCounts)]
+    lib.sg_train_begin.argtypes = [vp, C.POINTER(SgTrainSetup)]
+    lib.sg_train_feed.argtypes = [vp, C.c_char_p, C.c_uint64]
+    lib.sg_train_finish.argtypes = [vp, C.POINTER(SgTrainCounts), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.sg_train_end.argtypes = [vp]
+    lib.sg_train_end.restype = None
     lib.sg_build_haplotypes.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(SgHapPiece), C.c_uint64,
                                         C.c_char_p, C.c_uint64, C.POINTER(SgHapPatch), C.c_uint64]
     lib.sg_haplotype_codes.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p]

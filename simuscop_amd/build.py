@@ -3,6 +3,7 @@
   libsimuscop_amd.so  -- C ABI engine: HIP kernels for gfx950 + table conversion   (hipcc)
   libsimuscop_host.so -- C++ host side mirroring SimuSCoP's config/CLI surface      (g++)
   simuReads           -- `simuReads <config.txt>` command line, links the two above  (g++)
+  seqToProfile        -- the profile trainer's command line (host/train_main.cpp)     (g++)
 """
 from __future__ import annotations
 
@@ -19,8 +20,9 @@ INCLUDE = os.path.join(ROOT, "include")
 
 ENGINE_SRCS = ["sg_kernels.hip", "sg_haplotypes.hip", "sg_deflate.hip", "sg_train.hip", "sg_api.cpp", "sg_tables.cpp", "sg_deflate.cpp"]
 HOST_SRCS = ["host/config.cpp", "host/profile.cpp", "host/fasta.cpp", "host/variants.cpp", "host/genome.cpp",
-             "host/simulate.cpp"]
+             "host/simulate.cpp", "host/train.cpp"]
 CLI_SRCS = ["host/main.cpp"]
+TRAIN_CLI_SRCS = ["host/train_main.cpp"]
 
 
 def _newer(target, deps):
@@ -74,6 +76,14 @@ def build_host(force=False, verbose=False):
     if force or _newer(exe, cli + hdrs + [so]):
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", INCLUDE, "-I", CSRC] + cli + \
               ["-o", exe, "-L", LIBDIR, "-lsimuscop_host", "-lsimuscop_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    texe = os.path.join(LIBDIR, "seqToProfile")
+    tcli = [os.path.join(CSRC, s) for s in TRAIN_CLI_SRCS]
+    if force or _newer(texe, tcli + hdrs + [so]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", INCLUDE, "-I", CSRC] + tcli + \
+              ["-o", texe, "-L", LIBDIR, "-lsimuscop_host", "-lsimuscop_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -446,6 +446,26 @@ void Genome::build_chains(const std::string& popu, const std::string& chr, uint6
     }
     g.has_seq = true;
   }
+  // A fragment that runs off its segment goes on in chrSegs[index + 1 ...] (Segment.cpp:1085-1101), `index` being the
+  // number divideSegment gave the segment (Genome.cpp:741-763) -- its place in the list, except when the FASTA names a
+  // contig twice: the list then holds the contig's segments twice, numbered from 0 both times, and the LAST segment of the
+  // second round continues in the segment behind its own number instead of ending the chain (a single-segment contig: in
+  // itself).  The chains get those segments once more behind their end, as a tail no window lies in.
+  if (!plan.segs.empty() && (size_t)plan.segs.back().index + 1 < plan.segs.size()) {
+    for (size_t k = (size_t)plan.segs.back().index + 1; k < plan.segs.size(); k++) {
+      if (!plan.segs[k].has_seq) continue;
+      Segment tail = plan.segs[k];   // (a copy: the segment keeps its own place in the chains)
+      if (device_haps) {
+        segment_pieces(popu, chr, tail, plan);
+      } else {
+        segment_haplotypes(popu, chr, tail, haps);
+        for (int h = 0; h < ploidy; h++) {
+          plan.chains[h] += haps[h];
+          plan.chain_len[h] = plan.chains[h].size();
+        }
+      }
+    }
+  }
   plan.chains_built = true;
 }
 

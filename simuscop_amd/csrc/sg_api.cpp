@@ -234,6 +234,8 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+struct sg_train_session;
+
 struct sg_outputs {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -271,6 +273,7 @@ struct sg_ctx {
     std::vector<uint64_t> slot_first;           // planned fragments before each active segment; [n_active] = total
   } winfo;
   uint64_t ref_raw_bytes = 0;
+  struct sg_train_session* train = nullptr;   // profile training in progress (sg_train_begin .. sg_train_finish)
   std::vector<sg::DevContig> ref_contigs;  // host copy of the committed contig table
   uint64_t host_totals[4] = {0, 0, 0, 0};
   uint64_t host_flags[2] = {0, 0};  // totals[3..4] after the emit kernels: flags, slow-queue counts
@@ -422,6 +425,7 @@ void sg_destroy(sg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  sg_train_end(ctx);
   for (DevBuf* b : {&ctx->tab, &ctx->chains, &ctx->chains2, &ctx->chain_meta, &ctx->windows, &ctx->segmeta, &ctx->prefix, &ctx->pairs,
                     &ctx->win_actual, &ctx->win_namebase, &ctx->rlen, &ctx->events, &ctx->reclen, &ctx->recoff,
                     &ctx->meta, &ctx->totals, &ctx->bsum, &ctx->out1, &ctx->out2, &ctx->gcw, &ctx->gco, &ctx->gcm, &ctx->slowq,
@@ -769,127 +773,392 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// profile training, counting half (sg_train.hip)
+// profile training (sg_train.hip)
 // ------------------------------------------------------------------------------------------------
-int sg_train_count(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes, const char* const* contig_keys, uint32_t n_contigs,
-                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, sg_train_counts* out) {
-  if (!ctx || !out || (sam_bytes && !sam_text) || !bases || (n_contigs && !contig_keys)) return SG_ERR_INVALID;
-  if (ctx->ref_contigs.empty() || n_contigs != ctx->ref_contigs.size())
-    return ctx->fail(SG_ERR_INVALID, "sg_train_count: name the contigs of sg_reference_commit, in its order");
-  if (strlen(bases) != 4 || kmer < 1 || kmer > 6 || bins < 1 || n_isize < 1)
-    return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: bases must hold four letters, kmer 1..6, bins >= 1");
+struct sg_train_session {
+  char bases[4] = {0, 0, 0, 0};
+  uint32_t kmer = 0, bins = 0, n_isize = 0, n_indel_len = 0, count_gc = 0, window = 1000, wes = 0, remap = 0;
+  uint32_t kc = 0, koff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t subs_n = 0, kmers_n = 0, qual_n = 0, counters = 0;
+  uint32_t n_contigs = 0;
+  DevBuf keys, contigs, counts, flags, text, line_end, reads, gate, steps, windows, window_rc, carry, scan_work, tgt, known, t_ref, t_alt,
+      patch, gc_out;
+  bool own_codes = false;            // t_ref / t_alt are copies with the SNVs of the VCF in them
+  uint64_t code_bytes = 0;
+  uint64_t n_tgt = 0, n_ins = 0, n_del = 0;
+  int cur = 0;                       // carry[cur] is read by the next chunk, carry[cur ^ 1] written
+  uint64_t lines = 0, n_windows = 0; // lines fed / windows opened so far (host copies)
+  uint64_t windows_cap = 0;          // rows the window arrays hold
+  sg::TrainCarry* mail = nullptr;    // pinned
+  void release() {
+    for (DevBuf* b : {&keys, &contigs, &counts, &flags, &text, &line_end, &reads, &gate, &steps, &windows, &window_rc, &carry, &scan_work,
+                      &tgt, &known, &t_ref, &t_alt, &patch, &gc_out})
+      b->release();
+    if (mail) (void)hipHostFree(mail);
+    mail = nullptr;
+  }
+};
+
+void sg_train_end(sg_ctx* ctx) {
+  if (!ctx || !ctx->train) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->train->release();
+  delete ctx->train;
+  ctx->train = nullptr;
+}
+
+namespace {
+// a device buffer grown with what it holds kept (the window arrays live across chunks)
+int grow_keep(sg_ctx* ctx, DevBuf& buf, size_t keep_bytes, size_t want_bytes) {
+  if (want_bytes <= buf.cap) return SG_OK;
+  DevBuf bigger;
+  SG_ENSURE(bigger, want_bytes + want_bytes / 2);
+  if (keep_bytes) SG_HIP(hipMemcpyAsync(bigger.p, buf.p, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  buf.release();
+  buf = bigger;
+  return SG_OK;
+}
+}  // namespace
+
+int sg_train_begin(sg_ctx* ctx, const sg_train_setup* st) {
+  if (!ctx || !st || !st->bases || (st->n_contigs && !st->contig_keys)) return SG_ERR_INVALID;
+  if (ctx->ref_contigs.empty() || st->n_contigs != ctx->ref_contigs.size())
+    return ctx->fail(SG_ERR_INVALID, "sg_train_begin: name the contigs of sg_reference_commit, in its order");
+  if (strlen(st->bases) != 4 || st->kmer < 1 || st->kmer > 6 || st->bins < 1 || st->n_isize < 1 || st->n_indel_len < 1 || st->window < 1)
+    return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_begin: bases must hold four letters, kmer 1..6, bins >= 1");
+  if ((st->n_snv && !(st->snv_contig && st->snv_pos && st->snv_alt && st->snv_homo)) || (st->n_ins && !(st->ins_contig && st->ins_pos && st->ins_len)) ||
+      (st->n_del && !(st->del_contig && st->del_pos && st->del_len)) || (st->target_first && !(st->target_spos && st->target_epos)))
+    return SG_ERR_INVALID;
   uint32_t remap = 0;
   {
     const char nat[4] = {'A', 'C', 'T', 'G'};
     for (int n = 0; n < 4; n++) {
       int code = -1;
-      for (int k = 0; k < 4; k++) if (bases[k] == nat[n]) code = k;
-      if (code < 0) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: bases must be a permutation of ACGT");
+      for (int k = 0; k < 4; k++) if (st->bases[k] == nat[n]) code = k;
+      if (code < 0) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_begin: bases must be a permutation of ACGT");
       remap |= (uint32_t)code << (2 * n);
     }
   }
   SG_HIP(hipSetDevice(ctx->device));
-  // line starts (empty lines dropped); a last line without a line break gets one in the device copy
-  std::vector<uint64_t> off;
-  const bool open_end = sam_bytes && sam_text[sam_bytes - 1] != '\n';
-  for (uint64_t a = 0; a < sam_bytes;) {
-    const char* nl = (const char*)memchr(sam_text + a, '\n', sam_bytes - a);
-    const uint64_t e = nl ? (uint64_t)(nl - sam_text) : sam_bytes;
-    if (e > a) off.push_back(a);
-    a = e + 1;
-  }
-  const uint64_t n_lines = off.size();
-  // (line_off[i + 1] - 1 must be line i's break: offsets of dropped empty lines would break that, so lines are re-based)
-  std::vector<uint64_t> ends(n_lines + 1, 0);
-  std::string packed;
-  if (n_lines) {
-    packed.reserve(sam_bytes + 1);
-    for (uint64_t i = 0; i < n_lines; i++) {
-      const char* b = sam_text + off[i];
-      const char* nl = (const char*)memchr(b, '\n', sam_bytes - off[i]);
-      const uint64_t len = nl ? (uint64_t)(nl - b) : sam_bytes - off[i];
-      ends[i] = packed.size();
-      packed.append(b, len);
-      packed.push_back('\n');
-    }
-    ends[n_lines] = packed.size();
-  }
-  (void)open_end;
-  uint32_t kc = 0, koff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  sg_train_end(ctx);
+  sg_train_session* T = new sg_train_session();
+  ctx->train = T;
+  auto fail = [&](int rc) { sg_train_end(ctx); return rc; };
+  memcpy(T->bases, st->bases, 4);
+  T->kmer = (uint32_t)st->kmer; T->bins = (uint32_t)st->bins; T->n_isize = st->n_isize; T->n_indel_len = st->n_indel_len;
+  T->count_gc = st->count_gc ? 1u : 0u; T->window = st->window; T->remap = remap; T->n_contigs = st->n_contigs;
   {
     uint32_t p4 = 1;
-    for (int m = 1; m <= kmer; m++) { koff[m] = kc; p4 *= 4; kc += p4; }
+    for (int m = 1; m <= st->kmer; m++) { T->koff[m] = T->kc; p4 *= 4; T->kc += p4; }
   }
-  const size_t subs_n = (size_t)kc * bins * 4, kmers_n = (size_t)bins * kc, qual_n = (size_t)16 * bins * 94;
-  const size_t counters = 2 * subs_n + kmers_n + qual_n + n_isize + sg::kTrainScalars;
-  DevBuf d_text, d_off, d_keys, d_contigs, d_reads, d_counts, d_flags;
-  struct Free { DevBuf* b[7]; ~Free() { for (DevBuf* x : b) x->release(); } } freer{{&d_text, &d_off, &d_keys, &d_contigs, &d_reads, &d_counts, &d_flags}};
-  SG_ENSURE(d_text, packed.size() + 64);
-  SG_ENSURE(d_off, (n_lines + 1) * 8);
-  SG_ENSURE(d_keys, (size_t)n_contigs * sg::kTrainKeyBytes + 64);
-  SG_ENSURE(d_contigs, (size_t)n_contigs * sizeof(sg::TrainContig) + 64);
-  SG_ENSURE(d_reads, (n_lines + 1) * sizeof(sg::TrainRead));
-  SG_ENSURE(d_counts, counters * 8);
-  SG_ENSURE(d_flags, 64);
-  std::vector<char> keys((size_t)n_contigs * sg::kTrainKeyBytes, 0);
-  std::vector<sg::TrainContig> tc(n_contigs);
-  for (uint32_t c = 0; c < n_contigs; c++) {
-    if (!contig_keys[c] || strlen(contig_keys[c]) >= sg::kTrainKeyBytes) return ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_count: contig name too long");
-    strcpy(&keys[(size_t)c * sg::kTrainKeyBytes], contig_keys[c]);
-    tc[c] = sg::TrainContig{ctx->ref_contigs[c].code_off, ctx->ref_contigs[c].length};
-  }
+  T->subs_n = (size_t)T->kc * T->bins * 4; T->kmers_n = (size_t)T->bins * T->kc; T->qual_n = (size_t)16 * T->bins * 94;
+  T->counters = 2 * T->subs_n + T->kmers_n + T->qual_n + T->n_isize + 2 * (size_t)T->n_indel_len + sg::kTrainScalars;
+  const uint32_t nc = st->n_contigs;
   hipStream_t s = ctx->stream;
-  if (!packed.empty()) SG_HIP(hipMemcpyAsync(d_text.p, packed.data(), packed.size(), hipMemcpyHostToDevice, s));
-  SG_HIP(hipMemcpyAsync(d_off.p, ends.data(), (n_lines + 1) * 8, hipMemcpyHostToDevice, s));
-  if (n_contigs) {
-    SG_HIP(hipMemcpyAsync(d_keys.p, keys.data(), keys.size(), hipMemcpyHostToDevice, s));
-    SG_HIP(hipMemcpyAsync(d_contigs.p, tc.data(), tc.size() * sizeof(sg::TrainContig), hipMemcpyHostToDevice, s));
+  // ---- contigs, their targets (countGC's windows of an exome: [spos, epos - 1], Profile.cpp:590-593) ----
+  std::vector<char> keys((size_t)nc * sg::kTrainKeyBytes, 0);
+  std::vector<sg::TrainContig> tc(nc);
+  uint64_t code_bytes = 0;
+  for (uint32_t c = 0; c < nc; c++) {
+    if (!st->contig_keys[c] || strlen(st->contig_keys[c]) >= sg::kTrainKeyBytes) return fail(ctx->fail(SG_ERR_UNSUPPORTED, "sg_train_begin: contig name too long"));
+    strcpy(&keys[(size_t)c * sg::kTrainKeyBytes], st->contig_keys[c]);
+    memset(&tc[c], 0, sizeof tc[c]);
+    tc[c].code_off = ctx->ref_contigs[c].code_off;
+    tc[c].length = ctx->ref_contigs[c].length;
+    const std::string k = st->contig_keys[c];
+    tc[c].xym = (k == "X" || k == "Y" || k == "M") ? 1u : 0u;
+    code_bytes = std::max<uint64_t>(code_bytes, tc[c].code_off + ((tc[c].length + 15) / 16) * 16 + 64);
   }
-  SG_HIP(hipMemsetAsync(d_counts.p, 0, counters * 8, s));
-  SG_HIP(hipMemsetAsync(d_flags.p, 0, 64, s));
-  sg::TrainJob J;
-  memset(&J, 0, sizeof J);
-  J.text = d_text.as<char>();
-  J.line_off = d_off.as<uint64_t>();
-  J.n_lines = n_lines;
-  J.keys = d_keys.as<char>();
-  J.contigs = d_contigs.as<sg::TrainContig>();
-  J.n_contigs = n_contigs;
-  J.ref_codes = ctx->ref_codes.as<uint8_t>();
-  memcpy(J.bases, bases, 4);
-  J.remap = remap;
-  J.kmer = (uint32_t)kmer; J.bins = (uint32_t)bins; J.kmer_count = kc; J.n_isize = n_isize;
-  for (int m = 0; m < 8; m++) J.kmer_off[m] = koff[m];
-  J.reads = d_reads.as<sg::TrainRead>();
-  unsigned long long* c0 = d_counts.as<unsigned long long>();
-  J.subs1 = c0; J.subs2 = c0 + subs_n; J.kmers = c0 + 2 * subs_n; J.quality = J.kmers + kmers_n; J.isize = J.quality + qual_n;
-  J.scalars = J.isize + n_isize;
-  J.flags = d_flags.as<uint32_t>();
-  sg::launch_train(J, s);
-  SG_HIP(hipGetLastError());
-  std::vector<uint64_t> host(counters);
-  uint32_t flags = 0;
-  SG_HIP(hipMemcpyAsync(host.data(), d_counts.p, counters * 8, hipMemcpyDeviceToHost, s));
-  SG_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, s));
+  T->code_bytes = code_bytes;
+  std::vector<int64_t> tgt;   // left[n], right[n], pmax[n]
+  if (st->target_first && st->target_first[nc] > 0) {
+    const uint64_t n = st->target_first[nc];
+    T->n_tgt = n; T->wes = 1;
+    tgt.resize(3 * n);
+    for (uint32_t c = 0; c < nc; c++) {
+      const uint64_t a = st->target_first[c], b = st->target_first[c + 1];
+      if (b < a || b > n || b - a > 0xFFFFFFFFull) return fail(ctx->fail(SG_ERR_INVALID, "sg_train_begin: target_first must ascend"));
+      tc[c].tgt_first = a; tc[c].tgt_n = (uint32_t)(b - a);
+      int64_t pm = INT64_MIN;
+      for (uint64_t t = a; t < b; t++) {
+        // (loadTargets keeps 1 <= spos and epos <= the contig's length, divideTargets spos <= epos: Genome.cpp:270-279, 690-733)
+        if (st->target_spos[t] < 0 || st->target_epos[t] < st->target_spos[t] || (uint64_t)st->target_epos[t] > tc[c].length)
+          return fail(ctx->fail(SG_ERR_INVALID, "sg_train_begin: a target leaves its contig"));
+        tgt[t] = st->target_spos[t];
+        tgt[n + t] = st->target_epos[t] - 1;
+        pm = std::max(pm, tgt[n + t]);
+        tgt[2 * n + t] = pm;
+      }
+    }
+  }
+  // ---- known insertions / deletions per contig: file order (running maximum of the positions: where the reference's loop
+  // stops, Profile.cpp:314-316) and (position, length) order (is the event there at all, and how early) ----
+  std::vector<int64_t> kn64;   // per kind: pmax[n], pos[n]
+  std::vector<int32_t> kn32;   // per kind: len[n], first[n] (as int32)
+  auto stage_known = [&](uint64_t n, const uint32_t* contig, const int64_t* pos, const int32_t* len, bool ins) -> bool {
+    std::vector<std::vector<uint64_t>> rows(nc);
+    for (uint64_t i = 0; i < n; i++) {
+      if (contig[i] >= nc) return false;
+      rows[contig[i]].push_back(i);
+    }
+    const size_t b64 = kn64.size(), b32 = kn32.size();
+    kn64.resize(b64 + 2 * n);
+    kn32.resize(b32 + 2 * n);
+    uint64_t at = 0;
+    for (uint32_t c = 0; c < nc; c++) {
+      const std::vector<uint64_t>& r = rows[c];
+      if (r.size() > 0x7FFFFFFFull) return false;
+      (ins ? tc[c].ins_first : tc[c].del_first) = at;
+      (ins ? tc[c].ins_n : tc[c].del_n) = (uint32_t)r.size();
+      int64_t pm = INT64_MIN;
+      std::vector<uint32_t> order(r.size());
+      for (size_t j = 0; j < r.size(); j++) {
+        pm = std::max(pm, pos[r[j]]);
+        kn64[b64 + at + j] = pm;
+        order[j] = (uint32_t)j;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (pos[r[x]] != pos[r[y]]) return pos[r[x]] < pos[r[y]];
+        return len[r[x]] < len[r[y]];
+      });
+      for (size_t j = 0; j < r.size(); j++) {
+        kn64[b64 + n + at + j] = pos[r[order[j]]];
+        kn32[b32 + at + j] = len[r[order[j]]];
+        // the least file-order index of this (position, length): stable_sort keeps file order inside equal keys
+        const bool same = j > 0 && pos[r[order[j]]] == pos[r[order[j - 1]]] && len[r[order[j]]] == len[r[order[j - 1]]];
+        kn32[b32 + n + at + j] = same ? kn32[b32 + n + at + j - 1] : (int32_t)order[j];
+      }
+      at += r.size();
+    }
+    return true;
+  };
+  T->n_ins = st->n_ins; T->n_del = st->n_del;
+  if (!stage_known(st->n_ins, st->ins_contig, st->ins_pos, st->ins_len, true) || !stage_known(st->n_del, st->del_contig, st->del_pos, st->del_len, false))
+    return fail(ctx->fail(SG_ERR_INVALID, "sg_train_begin: a known insertion / deletion names no contig"));
+  // ---- SNVs: altSequence takes every one, refSequence the homozygous ones, later rows over earlier (Genome.cpp:469-475) ----
+  std::map<uint64_t, char> alt_patch, ref_patch;
+  for (uint64_t i = 0; i < st->n_snv; i++) {
+    if (st->snv_contig[i] >= nc) return fail(ctx->fail(SG_ERR_INVALID, "sg_train_begin: a known SNV names no contig"));
+    const sg::TrainContig& C = tc[st->snv_contig[i]];
+    // (a position outside the contig writes outside the reference's string: skipped)
+    if (st->snv_pos[i] < 1 || (uint64_t)st->snv_pos[i] > C.length) continue;
+    const uint64_t off = C.code_off + (uint64_t)(st->snv_pos[i] - 1);
+    alt_patch[off] = st->snv_alt[i];
+    if (st->snv_homo[i]) ref_patch[off] = st->snv_alt[i];
+  }
+  // ---- device side ----
+  auto up = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
+    SG_ENSURE(buf, bytes + 64);
+    if (bytes) SG_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
+    return SG_OK;
+  };
+  int rc;
+  if ((rc = up(T->keys, keys.data(), keys.size())) != SG_OK) return fail(rc);
+  if ((rc = up(T->contigs, tc.data(), tc.size() * sizeof(sg::TrainContig))) != SG_OK) return fail(rc);
+  if ((rc = up(T->tgt, tgt.data(), tgt.size() * 8)) != SG_OK) return fail(rc);
+  {
+    std::vector<uint8_t> blob(kn64.size() * 8 + kn32.size() * 4);
+    if (!kn64.empty()) memcpy(blob.data(), kn64.data(), kn64.size() * 8);
+    if (!kn32.empty()) memcpy(blob.data() + kn64.size() * 8, kn32.data(), kn32.size() * 4);
+    if ((rc = up(T->known, blob.data(), blob.size())) != SG_OK) return fail(rc);
+    SG_HIP(hipStreamSynchronize(s));
+  }
+  if (!alt_patch.empty()) {
+    T->own_codes = true;
+    SG_ENSURE(T->t_ref, code_bytes);
+    SG_ENSURE(T->t_alt, code_bytes);
+    SG_HIP(hipMemcpyAsync(T->t_ref.p, ctx->ref_codes.p, code_bytes, hipMemcpyDeviceToDevice, s));
+    SG_HIP(hipMemcpyAsync(T->t_alt.p, ctx->ref_codes.p, code_bytes, hipMemcpyDeviceToDevice, s));
+    for (int which = 0; which < 2; which++) {
+      const std::map<uint64_t, char>& m = which ? ref_patch : alt_patch;
+      if (m.empty()) continue;
+      std::vector<uint64_t> off; std::vector<uint8_t> ch;
+      off.reserve(m.size()); ch.reserve(m.size());
+      for (const auto& kv : m) { off.push_back(kv.first); ch.push_back((uint8_t)kv.second); }
+      SG_ENSURE(T->patch, off.size() * 9 + 64);
+      uint8_t* d_ch = T->patch.as<uint8_t>() + off.size() * 8;
+      SG_HIP(hipMemcpyAsync(T->patch.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, s));
+      SG_HIP(hipMemcpyAsync(d_ch, ch.data(), ch.size(), hipMemcpyHostToDevice, s));
+      sg::launch_train_patch((which ? T->t_ref : T->t_alt).as<uint8_t>(), T->patch.as<uint64_t>(), d_ch, off.size(), s);
+      SG_HIP(hipGetLastError());
+      SG_HIP(hipStreamSynchronize(s));
+    }
+  }
+  SG_ENSURE(T->counts, T->counters * 8);
+  SG_ENSURE(T->flags, 64);
+  SG_ENSURE(T->carry, 2 * sizeof(sg::TrainCarry) + 64);
+  SG_HIP(hipMemsetAsync(T->counts.p, 0, T->counters * 8, s));
+  SG_HIP(hipMemsetAsync(T->flags.p, 0, 64, s));
+  SG_HIP(hipMemsetAsync(T->carry.p, 0, 2 * sizeof(sg::TrainCarry), s));
+  SG_HIP(hipHostMalloc((void**)&T->mail, sizeof(sg::TrainCarry), hipHostMallocDefault));
   SG_HIP(hipStreamSynchronize(s));
-  if (flags & 1u) return ctx->fail(SG_ERR_INVALID, "sg_train_count: malformed read, there should be 11 mandatory fields");   // Profile.cpp:246-251
+  return SG_OK;
+}
+
+namespace {
+void train_job(sg_ctx* ctx, sg_train_session* T, sg::TrainJob& J) {
+  memset(&J, 0, sizeof J);
+  J.keys = T->keys.as<char>();
+  J.contigs = T->contigs.as<sg::TrainContig>();
+  J.n_contigs = T->n_contigs;
+  J.ref_codes = T->own_codes ? T->t_ref.as<uint8_t>() : ctx->ref_codes.as<uint8_t>();
+  J.alt_codes = T->own_codes ? T->t_alt.as<uint8_t>() : ctx->ref_codes.as<uint8_t>();
+  memcpy(J.bases, T->bases, 4);
+  J.remap = T->remap;
+  J.kmer = T->kmer; J.bins = T->bins; J.kmer_count = T->kc; J.n_isize = T->n_isize; J.n_indel_len = T->n_indel_len;
+  for (int m = 0; m < 8; m++) J.kmer_off[m] = T->koff[m];
+  J.count_gc = T->count_gc; J.wes = T->wes; J.window = T->window;
+  J.tgt_left = T->tgt.as<int64_t>(); J.tgt_right = J.tgt_left + T->n_tgt; J.tgt_pmax = J.tgt_left + 2 * T->n_tgt;
+  const int64_t* k64 = T->known.as<int64_t>();
+  const int32_t* k32 = (const int32_t*)(T->known.as<uint8_t>() + (2 * T->n_ins + 2 * T->n_del) * 8);
+  J.known_ins = sg::TrainKnown{k64, k64 + T->n_ins, k32, (const uint32_t*)(k32 + T->n_ins)};
+  J.known_del = sg::TrainKnown{k64 + 2 * T->n_ins, k64 + 2 * T->n_ins + T->n_del, k32 + 2 * T->n_ins, (const uint32_t*)(k32 + 2 * T->n_ins + T->n_del)};
+  unsigned long long* c0 = T->counts.as<unsigned long long>();
+  J.subs1 = c0; J.subs2 = c0 + T->subs_n; J.kmers = c0 + 2 * T->subs_n; J.quality = J.kmers + T->kmers_n; J.isize = J.quality + T->qual_n;
+  J.ins_len = J.isize + T->n_isize; J.del_len = J.ins_len + T->n_indel_len; J.scalars = J.del_len + T->n_indel_len;
+  J.flags = T->flags.as<uint32_t>();
+  J.carry_in = T->carry.as<sg::TrainCarry>() + T->cur;
+  J.carry_out = T->carry.as<sg::TrainCarry>() + (T->cur ^ 1);
+}
+}  // namespace
+
+int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
+  if (!ctx || (sam_bytes && !sam_text)) return SG_ERR_INVALID;
+  sg_train_session* T = ctx->train;
+  if (!T) return ctx->fail(SG_ERR_INVALID, "sg_train_feed: call sg_train_begin first");
+  if (!sam_bytes) return SG_OK;
+  SG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const bool open_end = sam_text[sam_bytes - 1] != '\n';   // a last line without a line break gets one in the device copy
+  const uint64_t bytes = sam_bytes + (open_end ? 1 : 0);
+  SG_ENSURE(T->text, bytes + 64);
+  SG_HIP(hipMemcpyAsync(T->text.p, sam_text, sam_bytes, hipMemcpyHostToDevice, s));
+  if (open_end) SG_HIP(hipMemsetAsync(T->text.as<char>() + sam_bytes, '\n', 1, s));
+  SG_ENSURE(T->scan_work, sg::train_scan_work_bytes(bytes / 64 + 1));
+  sg::TrainJob J;
+  train_job(ctx, T, J);
+  J.text = T->text.as<char>();
+  J.bytes = bytes;
+  J.scan_work = T->scan_work.p;
+  sg::launch_train_lines_count(J, s);
+  SG_HIP(hipGetLastError());
+  SG_HIP(hipMemcpyAsync(T->mail, J.carry_out, sizeof(sg::TrainCarry), hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  const uint64_t n_lines = T->mail->n_lines;
+  if (!n_lines) return SG_OK;
+  SG_ENSURE(T->line_end, n_lines * 8 + 64);
+  SG_ENSURE(T->reads, n_lines * sizeof(sg::TrainRead) + 64);
+  if (T->count_gc) {
+    SG_ENSURE(T->gate, n_lines * sizeof(sg::TrainGate) + 64);
+    SG_ENSURE(T->steps, n_lines * sizeof(sg::TrainStep) + 64);
+    const uint64_t want = T->n_windows + n_lines + 1;
+    if (want > T->windows_cap) {
+      const uint64_t cap = want + want / 2;
+      int rc;
+      if ((rc = grow_keep(ctx, T->windows, T->n_windows * sizeof(sg::TrainWindow), cap * sizeof(sg::TrainWindow))) != SG_OK) return rc;
+      if ((rc = grow_keep(ctx, T->window_rc, T->n_windows * 4, cap * 4)) != SG_OK) return rc;
+      SG_HIP(hipMemsetAsync(T->window_rc.as<uint32_t>() + T->n_windows, 0, (cap - T->n_windows) * 4, s));
+      T->windows_cap = cap;
+    }
+  }
+  SG_ENSURE(T->scan_work, sg::train_scan_work_bytes(std::max<uint64_t>(bytes / 64 + 1, n_lines)));
+  if (T->scan_work.p != J.scan_work) {   // (the tile prefixes of the line scan sit in the old block: count again)
+    J.scan_work = T->scan_work.p;
+    sg::launch_train_lines_count(J, s);
+  }
+  J.line_end = T->line_end.as<uint64_t>();
+  J.n_lines = n_lines;
+  J.reads = T->reads.as<sg::TrainRead>();
+  J.gate = T->gate.as<sg::TrainGate>();
+  J.steps = T->steps.as<sg::TrainStep>();
+  J.windows = T->windows.as<sg::TrainWindow>();
+  J.window_rc = T->window_rc.as<uint32_t>();
+  sg::launch_train_lines_fill(J, s);
+  sg::launch_train_chunk(J, s);
+  SG_HIP(hipGetLastError());
+  uint32_t flags = 0;
+  SG_HIP(hipMemcpyAsync(T->mail, J.carry_out, sizeof(sg::TrainCarry), hipMemcpyDeviceToHost, s));
+  SG_HIP(hipMemcpyAsync(&flags, T->flags.p, 4, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  if (flags & 1u) return ctx->fail(SG_ERR_INVALID, "Error: malformed read , there should be 11 mandatory fields");   // Profile.cpp:246-251
+  T->lines += n_lines;
+  if (T->count_gc) T->n_windows = T->mail->n_windows;
+  T->cur ^= 1;
+  return SG_OK;
+}
+
+int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, uint64_t gc_cap, uint64_t* n_gc) {
+  if (!ctx || !out) return SG_ERR_INVALID;
+  sg_train_session* T = ctx->train;
+  if (!T) return ctx->fail(SG_ERR_INVALID, "sg_train_finish: call sg_train_begin first");
+  SG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  // ---- the windows countGC pushed (Profile.cpp:559-570, 623-634): every window but the last one it was in, if its GC
+  // content is above zero and it counted a read; in the order they were opened ----
+  std::vector<double> h_gc, h_rc;
+  std::vector<uint32_t> h_raw;
+  const uint64_t nw = T->n_windows;
+  if (nw) {
+    SG_ENSURE(T->gc_out, nw * 16 + 64);
+    sg::TrainJob J;
+    train_job(ctx, T, J);
+    double* d_gc = T->gc_out.as<double>();
+    sg::launch_train_window_gc(T->windows.as<sg::TrainWindow>(), T->window_rc.as<uint32_t>(), nw, J.contigs, J.ref_codes, T->wes, d_gc, d_gc + nw, s);
+    SG_HIP(hipGetLastError());
+    h_gc.resize(nw); h_rc.resize(nw); h_raw.resize(nw);
+    SG_HIP(hipMemcpyAsync(h_gc.data(), d_gc, nw * 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipMemcpyAsync(h_rc.data(), d_gc + nw, nw * 8, hipMemcpyDeviceToHost, s));
+    SG_HIP(hipMemcpyAsync(h_raw.data(), T->window_rc.p, nw * 4, hipMemcpyDeviceToHost, s));
+  }
+  std::vector<uint64_t> host(T->counters);
+  SG_HIP(hipMemcpyAsync(host.data(), T->counts.p, T->counters * 8, hipMemcpyDeviceToHost, s));
+  SG_HIP(hipStreamSynchronize(s));
+  uint64_t pushed = 0;
+  for (uint64_t w = 0; w + 1 < nw; w++)
+    if (h_gc[w] > 0 && h_raw[w] > 0) {
+      if (pushed < gc_cap && gc && rc) { gc[pushed] = h_gc[w]; rc[pushed] = h_rc[w]; }
+      pushed++;
+    }
+  if (n_gc) *n_gc = pushed;
+  if (gc && rc && pushed > gc_cap) return ctx->fail(SG_ERR_OVERFLOW, "sg_train_finish: more (GC, read count) pairs than gc_cap");
   const uint64_t* h = host.data();
-  memcpy(out->subs1, h, subs_n * 8);
-  memcpy(out->subs2, h + subs_n, subs_n * 8);
-  memcpy(out->kmers, h + 2 * subs_n, kmers_n * 8);
-  memcpy(out->quality, h + 2 * subs_n + kmers_n, qual_n * 8);
-  memcpy(out->isize, h + 2 * subs_n + kmers_n + qual_n, (size_t)n_isize * 8);
-  const uint64_t* sc = h + 2 * subs_n + kmers_n + qual_n + n_isize;
-  memcpy(out->ins_len, sc + sg::kTrainInsLen, 256 * 8);
-  memcpy(out->del_len, sc + sg::kTrainDelLen, 256 * 8);
-  out->lines = n_lines;
+  if (out->subs1) memcpy(out->subs1, h, T->subs_n * 8);
+  if (out->subs2) memcpy(out->subs2, h + T->subs_n, T->subs_n * 8);
+  if (out->kmers) memcpy(out->kmers, h + 2 * T->subs_n, T->kmers_n * 8);
+  if (out->quality) memcpy(out->quality, h + 2 * T->subs_n + T->kmers_n, T->qual_n * 8);
+  const uint64_t* is = h + 2 * T->subs_n + T->kmers_n + T->qual_n;
+  if (out->isize) memcpy(out->isize, is, (size_t)T->n_isize * 8);
+  if (out->ins_len) memcpy(out->ins_len, is + T->n_isize, (size_t)T->n_indel_len * 8);
+  if (out->del_len) memcpy(out->del_len, is + T->n_isize + T->n_indel_len, (size_t)T->n_indel_len * 8);
+  const uint64_t* sc = is + T->n_isize + 2 * (size_t)T->n_indel_len;
+  out->lines = T->lines;
   out->reads_counted = sc[sg::kTrainReads];
   out->cigar_chars = sc[sg::kTrainCigarChars];
   out->insert_events = sc[sg::kTrainInsEvents];
   out->delete_events = sc[sg::kTrainDelEvents];
   out->isize_overflow = sc[sg::kTrainIsizeOverflow];
+  out->indel_len_overflow = sc[sg::kTrainIndelLenOverflow];
   out->skipped_overhang = sc[sg::kTrainOverhang];
+  out->gc_rejected = sc[sg::kTrainGcRejected];
+  out->gc_windows = nw;
+  sg_train_end(ctx);
   return SG_OK;
+}
+
+int sg_train_count(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes, const char* const* contig_keys, uint32_t n_contigs,
+                   const char* bases, int32_t kmer, int32_t bins, uint32_t n_isize, uint32_t n_indel_len, sg_train_counts* out) {
+  if (!ctx || !out) return SG_ERR_INVALID;
+  sg_train_setup st;
+  memset(&st, 0, sizeof st);
+  st.contig_keys = contig_keys; st.n_contigs = n_contigs; st.bases = bases; st.kmer = kmer; st.bins = bins;
+  st.n_isize = n_isize; st.n_indel_len = n_indel_len; st.count_gc = 0; st.window = 1000;
+  int rc = sg_train_begin(ctx, &st);
+  if (rc == SG_OK) rc = sg_train_feed(ctx, sam_text, sam_bytes);
+  if (rc == SG_OK) rc = sg_train_finish(ctx, out, nullptr, nullptr, 0, nullptr);
+  if (rc != SG_OK) sg_train_end(ctx);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -55,7 +55,9 @@ struct DevContig {
 
 // lane = 16 consecutive bases of one contig.  Line structure is verified on the way: a line break
 // byte that is not '\n' / '\r', or a line break byte inside a line, sets flag 2 (the host then falls
-// back to its general parser).
+// back to its general parser).  An image without line ends (line_width == line_bases: what the general
+// parser uploads, one line per contig) may hold carriage returns: fastahack keeps them as bases
+// (Fasta.cpp:150-199) and so does the default reading here; they encode as "other".
 __global__ __launch_bounds__(256) void ref_ingest_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ codes,
                                                          const DevContig* __restrict__ contigs, uint32_t n_contigs,
                                                          uint64_t n_blocks, uint32_t* __restrict__ flags) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void ref_ingest_kernel(const uint8_t* __restri
     const uint32_t nb = (uint32_t)(c.length - i0 < 16 ? c.length - i0 : 16);
     for (uint32_t k = 0; k < nb; k++) {
       const uint32_t b = raw[src];
-      bad |= (b == '\n') | (b == '\r');
+      bad |= (b == '\n') | ((b == '\r') & (nl != 0u));
       out[k >> 2] = (out[k >> 2] & ~(0xFFu << ((k & 3) * 8))) | (encode_base(b) << ((k & 3) * 8));
       src++;
       if (++r == c.line_bases) {

@@ -1348,7 +1348,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   // L2: WRITE_SIZE 6.43 -> see profiles/r03_final.)
   const bool tail_whole = ((uint32_t)P.L & 7u) == 7u && ((uint32_t)P.L + 7u) / 8u == TI;
   const uint32_t TIp = tail_whole ? TI : TI - 1u;
-  const uint32_t TI16 = TIp >> 1;                             // 16-base items per plain read (the plain16 steps below)
+  // 16-base items per plain read (the plain16 steps below).  A whole last item of seven bases (tail_whole) carries the line
+  // break and the "+" line and only the 8-base steps write those: it stays out of the pairs (L = 303: 38 items, 18 pairs +
+  // items 36 and 37 on their own; found by fuzz seeds 222 / 224, whose 303-base reads lost their line break to a sixteenth base)
+  const uint32_t TI16 = (tail_whole ? TIp - 1u : TIp) >> 1;
   const uint32_t inv_TI16 = TI16 ? (1u << 20) / TI16 + 1u : 0u;   // ceil-reciprocal (i / TI16 exact while i * TI16 < 2^20)
 
   // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one

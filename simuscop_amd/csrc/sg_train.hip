@@ -1,14 +1,22 @@
-// sg_train.hip -- profile training, counting half: what Profile::processRead
-// (lib/profile/Profile.cpp:228-510) adds to its count matrices, for lines of `samtools view` text.
+// sg_train.hip -- profile training on the device: what Profile::train (lib/profile/Profile.cpp:1442-1484)
+// gathers from lines of `samtools view` text, chunk of lines by chunk of lines, in file order.
 //
-//   train_parse_kernel   lane = line: the eleven mandatory fields, the filters of :262-288, the CIGAR walk of :294-388
-//                        (insertion / deletion length counts; only a single nM goes on), the read's place on the
-//                        resident reference codes -> one descriptor per line
-//   train_count_kernel   wave = read, lane = base: k-mer context of the reference bases in read orientation
-//                        (Profile::getKmerIndx order, :70-124, :220-226), bin = i * bins / n, then the three counters
-//                        of :421-441 and :455-480 as 64-bit atomics; the insert size (:445-450) by lane 0
-// Integer work throughout; results are exact counts.  Not restated: Profile::countGC (:512-703) -- sequential over the
-// file -- and known variants (the VCF side of seqToProfile); see oracle/train_oracle.cpp.
+//   train_lines_*         line breaks of the chunk -> offsets (a scan over 64-byte blocks)
+//   train_fields_kernel   lane = line: the eleven mandatory fields and the filters of Profile::processRead (:244-279)
+//   gate scan             the lines that reach Profile::countGC (:281-287), compacted in file order
+//   state scan            Profile::countGC (:512-703) without its sequential loop.  Its state -- the window reads are being
+//                         counted in -- only ever moves forward inside a run of reads of one contig, and is a function of
+//                         the LARGEST position the run has shown so far: the grid window holding it (whole genome), or the
+//                         first target that ends at or behind it (exome; proof in DESIGN.md section 8).  A segmented
+//                         running maximum therefore gives every read the state it finds, and with it the verdict the
+//                         reference reaches: turned away (behind the window), counted in it, or opening the next one
+//   window scan           windows opened so far -> the read's window; read counts by atomics (one per thread and window)
+//   train_cigar_kernel    lane = counted line: the CIGAR walk of :290-382 (insertion / deletion length counts unless the VCF
+//                         knows the event; only a single nM goes on)
+//   train_count_kernel    wave = read, lane = base: subsDist1 / subsDist2 / kmersDist (:399-442), iSizeDist (:444-451),
+//                         qualityDist (:453-481) as 64-bit atomics
+//   train_window_gc_kernel (at the end) wave = window: calculateGCContent (lib/mydefine/MyDefine.cpp:306-331)
+// Integer work throughout; results are exact counts.  The checker is oracle/train_oracle.cpp.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -16,6 +24,270 @@
 #include "sg_train.h"
 
 namespace sg {
+
+namespace {
+
+constexpr uint32_t kScanThreads = 256, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
+
+// ---- a device-wide scan in three launches: tile aggregates, the spine (one workgroup, carries the value of the chunk
+// before in and the total out), the tiles again with their prefixes.  Op: T, identity(), n(), load(i), combine(a, b)
+// (associative, a before b), store(i, exclusive, inclusive), finish(), carry_in(), carry_out(total).
+template <class T, class Op>
+__device__ __forceinline__ T block_inclusive(T v, T* lds, Op& op) {
+  const uint32_t t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < kScanThreads; off <<= 1) {
+    T x = lds[t];
+    if (t >= off) x = op.combine(lds[t - off], x);
+    __syncthreads();
+    lds[t] = x;
+    __syncthreads();
+  }
+  return lds[t];
+}
+
+template <class Op>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Op op, typename Op::T* tile_sum) {
+  using T = typename Op::T;
+  __shared__ T lds[kScanThreads];
+  const uint64_t n = op.n();
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  T acc = op.identity();
+  for (uint32_t k = 0; k < kScanItems; k++)
+    if (base + k < n) acc = op.combine(acc, op.load(base + k));
+  const T inc = block_inclusive(acc, lds, op);
+  if (threadIdx.x == kScanThreads - 1) tile_sum[blockIdx.x] = inc;
+}
+
+template <class Op>
+__global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(Op op, typename Op::T* tile_sum, uint32_t n_tiles) {
+  using T = typename Op::T;
+  __shared__ T lds[kScanThreads];
+  T carry = op.carry_in();
+  for (uint32_t b = 0; b < n_tiles; b += kScanThreads) {
+    const uint32_t i = b + threadIdx.x;
+    const T v = i < n_tiles ? tile_sum[i] : op.identity();
+    const T inc = block_inclusive(v, lds, op);
+    const T before = threadIdx.x ? lds[threadIdx.x - 1] : op.identity();
+    const T last = lds[kScanThreads - 1];
+    __syncthreads();
+    if (i < n_tiles) tile_sum[i] = op.combine(carry, before);   // exclusive prefix of tile i
+    carry = op.combine(carry, last);
+    (void)inc;
+  }
+  if (threadIdx.x == 0) op.carry_out(carry);
+}
+
+template <class Op>
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Op op, const typename Op::T* tile_excl) {
+  using T = typename Op::T;
+  __shared__ T lds[kScanThreads];
+  const uint64_t n = op.n();
+  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  T acc = op.identity();
+  for (uint32_t k = 0; k < kScanItems; k++)
+    if (base + k < n) acc = op.combine(acc, op.load(base + k));
+  block_inclusive(acc, lds, op);
+  T run = op.combine(tile_excl[blockIdx.x], threadIdx.x ? lds[threadIdx.x - 1] : op.identity());
+  for (uint32_t k = 0; k < kScanItems; k++) {
+    if (base + k >= n) break;
+    const T inc = op.combine(run, op.load(base + k));
+    op.store(base + k, run, inc);
+    run = inc;
+  }
+  op.finish();
+}
+
+template <class Op>
+void run_scan_count(Op op, uint64_t n_bound, void* work, hipStream_t s) {   // tile aggregates and the spine (total -> carry_out)
+  using T = typename Op::T;
+  const uint32_t n_tiles = (uint32_t)((n_bound + kScanTile - 1) / kScanTile);
+  T* tiles = (T*)work;
+  if (n_tiles) hipLaunchKernelGGL(scan_reduce_kernel<Op>, dim3(n_tiles), dim3(kScanThreads), 0, s, op, tiles);
+  hipLaunchKernelGGL(scan_spine_kernel<Op>, dim3(1), dim3(kScanThreads), 0, s, op, tiles, n_tiles);
+}
+template <class Op>
+void run_scan_apply(Op op, uint64_t n_bound, void* work, hipStream_t s) {
+  using T = typename Op::T;
+  const uint32_t n_tiles = (uint32_t)((n_bound + kScanTile - 1) / kScanTile);
+  if (n_tiles) hipLaunchKernelGGL(scan_apply_kernel<Op>, dim3(n_tiles), dim3(kScanThreads), 0, s, op, (const T*)work);
+}
+template <class Op>
+void run_scan(Op op, uint64_t n_bound, void* work, hipStream_t s) {
+  run_scan_count(op, n_bound, work, s);
+  run_scan_apply(op, n_bound, work, s);
+}
+
+// ---- line breaks: element = 64 bytes of text, value = its line breaks ----
+struct LineOp {
+  using T = uint64_t;
+  TrainJob J;
+  __device__ T identity() const { return 0; }
+  __device__ uint64_t n() const { return (J.bytes + 63) / 64; }
+  __device__ T combine(T a, T b) const { return a + b; }
+  __device__ T load(uint64_t i) const {
+    const uint64_t a = i * 64, e = a + 64 < J.bytes ? a + 64 : J.bytes;
+    uint32_t c = 0;
+    if (e - a == 64) {   // (the text buffer is 16-byte aligned)
+      const uint4* p = (const uint4*)(J.text + a);
+      for (int q = 0; q < 4; q++) {
+        const uint4 v = p[q];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; k++) {
+          const uint32_t x = w[k] ^ 0x0A0A0A0Au;                       // zero bytes where a line break stands
+          const uint32_t z = ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) | 0x7F7F7F7Fu);   // 0x80 in exactly those bytes
+          c += (uint32_t)__popc(z);
+        }
+      }
+    } else {
+      for (uint64_t b = a; b < e; b++) c += J.text[b] == '\n';
+    }
+    return c;
+  }
+  __device__ void store(uint64_t i, T excl, T) const {
+    const uint64_t a = i * 64, e = a + 64 < J.bytes ? a + 64 : J.bytes;
+    uint64_t k = excl;
+    for (uint64_t b = a; b < e; b++)
+      if (J.text[b] == '\n') J.line_end[k++] = b;
+  }
+  __device__ void finish() const {}
+  __device__ T carry_in() const { return 0; }
+  __device__ void carry_out(T total) const { J.carry_out->n_lines = total; }
+};
+
+// ---- the reads countGC sees, compacted in file order ----
+struct GateOp {
+  using T = uint64_t;
+  TrainJob J;
+  __device__ T identity() const { return 0; }
+  __device__ uint64_t n() const { return J.n_lines; }
+  __device__ T combine(T a, T b) const { return a + b; }
+  __device__ T load(uint64_t i) const { return J.reads[i].flags & 1u; }
+  __device__ void store(uint64_t i, T excl, T) const {
+    const TrainRead R = J.reads[i];
+    if (R.flags & 1u) J.gate[excl] = TrainGate{R.pos0, R.contig, (uint32_t)i};
+  }
+  __device__ void finish() const {}
+  __device__ T carry_in() const { return 0; }
+  __device__ void carry_out(T total) const { J.carry_out->n_gated = total; }
+};
+
+// ---- countGC's state: segmented running maximum of the positions (a run = consecutive reads of one contig), and the
+// least contig length met so far (winSize shrinks to it for good, :645-648) ----
+struct StateVal { int64_t max_pos, ref_min; uint32_t head, pad; };
+
+__device__ __forceinline__ uint64_t first_at_or_above(const int64_t* a, uint64_t n, int64_t p) {   // first k with a[k] >= p (a ascending)
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (a[mid] >= p) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+struct StateOp {
+  using T = StateVal;
+  TrainJob J;
+  __device__ T identity() const { return StateVal{INT64_MIN, INT64_MAX, 0u, 0u}; }
+  __device__ uint64_t n() const { return J.carry_out->n_gated; }
+  __device__ T combine(const T& a, const T& b) const {
+    T r;
+    r.head = a.head | b.head;
+    r.max_pos = b.head ? b.max_pos : (a.max_pos > b.max_pos ? a.max_pos : b.max_pos);
+    r.ref_min = a.ref_min < b.ref_min ? a.ref_min : b.ref_min;
+    r.pad = 0;
+    return r;
+  }
+  __device__ bool head_of(uint64_t d, uint32_t contig) const {
+    if (d) return J.gate[d - 1].contig != contig;
+    return !J.carry_in->has || J.carry_in->last_contig != contig;
+  }
+  __device__ T load(uint64_t d) const {
+    const TrainGate g = J.gate[d];
+    return StateVal{g.pos0, (int64_t)J.contigs[g.contig].length, head_of(d, g.contig) ? 1u : 0u, 0u};
+  }
+  // the window countGC is in once the largest position of the run is m
+  __device__ void window_of(const TrainContig& C, int64_t m, int64_t ws, int64_t* left, int64_t* right, bool* none) const {
+    *none = false;
+    if (!J.wes) {                                        // :572-577, :650-657
+      int64_t r = (m / ws + 1) * ws - 1;
+      if (r > (int64_t)C.length - 1) r = (int64_t)C.length - 1;
+      *right = r; *left = r - ws + 1;
+    } else {                                             // :582-611, :662-690
+      const uint64_t t = first_at_or_above(J.tgt_pmax + C.tgt_first, C.tgt_n, m);
+      if (t < C.tgt_n) { *left = J.tgt_left[C.tgt_first + t]; *right = J.tgt_right[C.tgt_first + t]; }
+      else { *left = *right = (int64_t)C.length; *none = true; }
+    }
+  }
+  __device__ void store(uint64_t d, const T& excl, const T& inc) const {
+    const TrainGate g = J.gate[d];
+    const TrainContig C = J.contigs[g.contig];
+    int64_t ws = (int64_t)J.window;
+    if (inc.ref_min < ws) ws = inc.ref_min;
+    const bool head = head_of(d, g.contig);
+    TrainStep S;
+    S.opens = 0; S.counted = 0; S.left = S.right = 0; S.ws = (uint32_t)ws; S.pad = 0;
+    int64_t l, r;
+    bool none;
+    bool open_now = head;
+    if (!head) {
+      window_of(C, excl.max_pos, ws, &l, &r, &none);
+      if (g.pos0 < l) { J.steps[d] = S; return; }        // :552-554
+      if (g.pos0 <= r) { S.counted = 1; S.left = l; S.right = r; J.steps[d] = S; return; }   // :555-558
+      open_now = true;
+    }
+    if (open_now) {
+      window_of(C, g.pos0, ws, &l, &r, &none);
+      S.opens = 1; S.left = l; S.right = r;
+      S.counted = J.wes ? ((!none && l <= g.pos0) ? 1u : 0u) : 1u;   // :579, :594-599, :659, :673-678
+      if (none) S.pad = 1;
+    }
+    J.steps[d] = S;
+  }
+  __device__ void finish() const {}
+  __device__ T carry_in() const {
+    return StateVal{J.carry_in->has ? J.carry_in->max_pos : INT64_MIN, J.carry_in->has ? J.carry_in->ref_min : INT64_MAX, 0u, 0u};
+  }
+  __device__ void carry_out(const T& total) const {   // (the gate list is complete by now: this spine runs after the gate scan)
+    J.carry_out->max_pos = total.max_pos;
+    J.carry_out->ref_min = total.ref_min;
+    const uint64_t n = J.carry_out->n_gated;
+    if (n) { J.carry_out->last_contig = J.gate[n - 1].contig; J.carry_out->has = 1u; }
+    else { J.carry_out->last_contig = J.carry_in->last_contig; J.carry_out->has = J.carry_in->has; }
+  }
+};
+
+// ---- windows opened so far -> the window of every read; read counts ----
+struct WindowOp {
+  using T = uint64_t;
+  TrainJob J;
+  uint64_t cur = ~0ull;   // (per thread: the window its last reads were counted in)
+  uint32_t cnt = 0;
+  __device__ T identity() const { return 0; }
+  __device__ uint64_t n() const { return J.carry_out->n_gated; }
+  __device__ T combine(T a, T b) const { return a + b; }
+  __device__ T load(uint64_t d) const { return J.steps[d].opens; }
+  __device__ void store(uint64_t d, T, T inc) {
+    const TrainStep S = J.steps[d];
+    const uint64_t id = inc - 1;     // (carry_in = the windows of the chunks before; a first read that opens nothing rides in
+                                     //  their last window)
+    if (S.opens) J.windows[id] = TrainWindow{S.left, S.right, J.gate[d].contig, S.pad ? 0u : S.ws};
+    if (S.counted) {
+      J.reads[J.gate[d].line].flags |= 8u;
+      if (id != cur) { finish(); cur = id; }
+      cnt++;
+    } else {
+      atomicAdd(J.scalars + kTrainGcRejected, 1ull);
+    }
+  }
+  __device__ void finish() {
+    if (cnt) atomicAdd(J.window_rc + cur, cnt);
+    cnt = 0;
+  }
+  __device__ T carry_in() const { return J.carry_in->n_windows; }
+  __device__ void carry_out(T total) const { J.carry_out->n_windows = total; }
+};
 
 __device__ __forceinline__ bool is_digit(char c) { return c >= '0' && c <= '9'; }
 
@@ -40,13 +312,15 @@ __device__ void abbr_of_chr(const char*& p, const char* e) {
   }
 }
 
-__global__ __launch_bounds__(256) void train_parse_kernel(TrainJob J) {
+__global__ __launch_bounds__(256) void train_fields_kernel(TrainJob J) {
   const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= J.n_lines) return;
   TrainRead R;
-  R.len = 0; R.flags = 0; R.tlen = 0; R.seq_off = R.qual_off = R.ref_off = 0;
-  const char* p = J.text + J.line_off[li];
-  const char* le = J.text + J.line_off[li + 1] - 1;  // the line break
+  R.len = 0; R.flags = 0; R.tlen = 0; R.seq_off = R.qual_off = R.ref_off = R.cigar_off = 0; R.cigar_len = 0; R.pos0 = 0; R.contig = 0; R.pad = 0;
+  const char* p = J.text + (li ? J.line_end[li - 1] + 1 : 0);
+  const char* le = J.text + J.line_end[li];  // the line break
+  auto done = [&]() { J.reads[li] = R; };
+  if (p == le) { done(); return; }           // an empty line: processRead returns at once (:229-231)
   // ---- the first eleven fields (:244-251) ----
   const char* fb[11];
   const char* fe[11];
@@ -58,17 +332,16 @@ __global__ __launch_bounds__(256) void train_parse_kernel(TrainJob J) {
       a = q + 1;
     }
   }
-  auto done = [&]() { J.reads[li] = R; };
   if (nf < 11) { atomicOr(J.flags, 1u); done(); return; }
   const long long position = field_int(fb[3], fe[3]);
   const int mapq = (int)field_int(fb[4], fe[4]);
   const int tlen = (int)field_int(fb[8], fe[8]);
-  if (position == 0) { done(); return; }                 // :262
-  if (mapq < 15) { done(); return; }                     // :266
+  if (position == 0) { done(); return; }                 // :263
+  if (mapq < 15) { done(); return; }                     // :267
   const char* cb = fb[2];
   abbr_of_chr(cb, fe[2]);
   int contig = -1;
-  for (uint32_t c = 0; c < J.n_contigs; c++) {           // :270-274
+  for (uint32_t c = 0; c < J.n_contigs; c++) {           // :271-275
     const char* key = J.keys + (size_t)c * kTrainKeyBytes;
     uint32_t i = 0;
     while (cb + i < fe[2] && key[i] != 0 && key[i] == cb[i]) i++;
@@ -76,52 +349,131 @@ __global__ __launch_bounds__(256) void train_parse_kernel(TrainJob J) {
   }
   if (contig < 0) { done(); return; }
   const uint32_t slen = (uint32_t)(fe[9] - fb[9]);
-  if (slen == 1 && fb[9][0] == '*') { done(); return; }  // :276
-  // ---- CIGAR (:294-388) ----
-  const char* cg = fb[5];
-  const int n_c = (int)(fe[5] - fb[5]);
-  atomicAdd(J.scalars + kTrainCigarChars, (unsigned long long)n_c);   // `baseCount += n`, n = strlen(cigar) (:296)
-  int sIndx = 0, k = 0;
-  bool hard = false;
-  for (int i = 0; i < n_c; i++) {
-    const char c = cg[i];
-    if (is_digit(c)) { k++; continue; }
-    if (c == 'H') { atomicAdd(J.scalars + kTrainCigarChars, (unsigned long long)(-(long long)n_c)); hard = true; break; }   // :302-305
-    if (c == 'S') sIndx = i + 1;
-    else if (c == 'I' || c == 'D') {                     // :309-368 (no known variants: every event counts)
-      const long long len = field_int(cg + sIndx, cg + i);
-      unsigned long long* row = J.scalars + (c == 'I' ? kTrainInsLen : kTrainDelLen);
-      if (len >= 0 && len < 256) atomicAdd(row + len, 1ull);
-      atomicAdd(J.scalars + (c == 'I' ? kTrainInsEvents : kTrainDelEvents), 1ull);
-      sIndx = i + 1;
-    } else sIndx = i + 1;
-  }
-  if (hard) { done(); return; }
-  if (n_c == 0 || k != n_c - 1 || cg[n_c - 1] != 'M') { done(); return; }   // :386-388
+  if (slen == 1 && fb[9][0] == '*') { done(); return; }  // :277
   const TrainContig C = J.contigs[contig];
-  if ((uint64_t)(position - 1) + slen > C.length) { atomicAdd(J.scalars + kTrainOverhang, 1ull); done(); return; }
   R.len = slen;
   R.tlen = tlen;
   R.seq_off = (uint64_t)(fb[9] - J.text);
   R.qual_off = (uint64_t)(fb[10] - J.text);
-  R.ref_off = C.code_off + (uint64_t)(position - 1);
-  R.flags = 1u | (tlen < 0 ? 2u : 0u) | ((uint32_t)(fe[10] - fb[10]) == slen ? 4u : 0u);
+  R.cigar_off = (uint64_t)(fb[5] - J.text);
+  R.cigar_len = (uint32_t)(fe[5] - fb[5]);
+  R.pos0 = position - 1;
+  R.contig = (uint32_t)contig;
+  R.flags = (tlen < 0 ? 2u : 0u) | ((uint32_t)(fe[10] - fb[10]) == slen ? 4u : 0u);
+  if (J.count_gc) {
+    if (C.xym) { atomicAdd(J.scalars + kTrainGcRejected, 1ull); done(); return; }   // :532-535
+    // a read that starts behind its contig's end makes the reference throw (std::string::substr, Genome.cpp:435); one on an
+    // empty contig never counts: both stay out of countGC's sight here
+    if (position - 1 < 0 || (uint64_t)(position - 1) >= C.length) { atomicAdd(J.scalars + kTrainOverhang, 1ull); done(); return; }
+    R.flags |= 1u;
+  } else {
+    R.flags |= 1u | 8u;   // (sg_train_count: every read through the filters is counted)
+  }
   done();
+}
+
+// is (pos, len) among the known events the reference's loop reaches (Profile.cpp:313-321, :343-351)?  The loop walks the
+// contig's list in file order and stops at the first position above pos.
+__device__ bool known_event(const TrainKnown& K, uint64_t first, uint32_t n, int64_t pos, int32_t len) {
+  if (!n) return false;
+  uint64_t lo = 0, hi = n;                                // first file-order index whose running maximum exceeds pos
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (K.pmax[first + mid] > pos) hi = mid; else lo = mid + 1;
+  }
+  const uint64_t stop = lo;
+  lo = 0; hi = n;                                         // first row >= (pos, len)
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const int64_t p = K.pos[first + mid];
+    const int32_t l = K.len[first + mid];
+    if (p > pos || (p == pos && l >= len)) hi = mid; else lo = mid + 1;
+  }
+  if (lo >= n || K.pos[first + lo] != pos || K.len[first + lo] != len) return false;
+  return K.first[first + lo] < stop;
+}
+
+__global__ __launch_bounds__(256) void train_cigar_kernel(TrainJob J) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= J.n_lines) return;
+  TrainRead R = J.reads[li];
+  if (!(R.flags & 8u)) return;
+  const TrainContig C = J.contigs[R.contig];
+  // ---- CIGAR (:290-382) ----
+  const char* cg = J.text + R.cigar_off;
+  const int n_c = (int)R.cigar_len;
+  atomicAdd(J.scalars + kTrainCigarChars, (unsigned long long)n_c);   // `baseCount += n`, n = strlen(cigar) (:294)
+  int sIndx = 0, k = 0;
+  long long refIndx = 0;
+  const long long position = R.pos0 + 1;
+  for (int i = 0; i < n_c; i++) {
+    const char c = cg[i];
+    if (is_digit(c)) { k++; continue; }
+    if (c == 'H') { atomicAdd(J.scalars + kTrainCigarChars, (unsigned long long)(-(long long)n_c)); return; }   // :300-303
+    if (c == 'S') sIndx = i + 1;
+    else if (c == 'I' || c == 'D') {                     // :307-367
+      const long long len = field_int(cg + sIndx, cg + i);
+      const bool ins = c == 'I';
+      const long long pos = ins ? position + refIndx - 1 : position + refIndx;
+      const bool found = ins ? known_event(J.known_ins, C.ins_first, C.ins_n, pos, (int32_t)len)
+                             : known_event(J.known_del, C.del_first, C.del_n, pos, (int32_t)len);
+      if (!found) {
+        unsigned long long* row = ins ? J.ins_len : J.del_len;
+        if (len >= 0 && len < (long long)J.n_indel_len) atomicAdd(row + len, 1ull);
+        else atomicAdd(J.scalars + kTrainIndelLenOverflow, 1ull);
+        atomicAdd(J.scalars + (ins ? kTrainInsEvents : kTrainDelEvents), 1ull);
+      }
+      if (!ins) refIndx += len;
+      sIndx = i + 1;
+    } else if (c == 'M') {
+      refIndx += field_int(cg + sIndx, cg + i);
+      sIndx = i + 1;
+    } else sIndx = i + 1;
+  }
+  if (n_c == 0 || k != n_c - 1 || cg[n_c - 1] != 'M') return;   // :380-382
+  // the reference indexes refSeq past its end when the read hangs over its contig (:458 with n = strlen(readSeq)): skipped
+  if ((uint64_t)R.pos0 + R.len > C.length) { atomicAdd(J.scalars + kTrainOverhang, 1ull); return; }
+  R.ref_off = C.code_off + (uint64_t)R.pos0;
+  J.reads[li].ref_off = R.ref_off;
+  J.reads[li].flags = R.flags | 16u;
 }
 
 __global__ __launch_bounds__(256) void train_count_kernel(TrainJob J) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   const uint32_t K = J.kmer, bins = J.bins, kc = J.kmer_count;
+  const bool has_alt = J.alt_codes != J.ref_codes;
   for (uint64_t li = wave; li < J.n_lines; li += n_waves) {
     const TrainRead R = J.reads[li];
-    if (!(R.flags & 1u)) continue;
-    const bool rev = (R.flags & 2u) != 0u;               // tlen < 0: everything reverse-complemented, mate 2 (:394-403)
+    if (!(R.flags & 16u)) continue;
+    const bool rev = (R.flags & 2u) != 0u;               // tlen < 0: everything reverse-complemented, mate 2 (:388-397)
     const uint32_t n = R.len;
     unsigned long long* subs = rev ? J.subs2 : J.subs1;
     const char* seq = J.text + R.seq_off;
     const char* qual = J.text + R.qual_off;
     const uint8_t* ref = J.ref_codes + R.ref_off;
+    const uint8_t* alt = J.alt_codes + R.ref_off;
+    // index in `bases` of the base the k-mer context holds at read position q (:404-415: the alternative allele where the
+    // read shows it, else the reference base), and whether the read shows the alternative allele there
+    auto context_idx = [&](uint32_t q, bool* is_alt) -> int {
+      const uint32_t w = rev ? n - 1u - q : q;
+      uint32_t code = ref[w];
+      *is_alt = false;
+      if (has_alt) {
+        const uint32_t ac = alt[w];
+        if (ac != code) {
+          const char c = seq[w];
+          bool eq;
+          if (ac <= 3u) eq = c == "ACTG"[ac];
+          else eq = rev ? !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't')   // (both complement to 'N')
+                        : (ac == 4u && c == 'N');
+          if (eq) { code = ac; *is_alt = true; }
+        }
+      }
+      if (code > 3u) return -1;
+      if (rev) code ^= 2u;
+      return (int)((J.remap >> (2u * code)) & 3u);
+    };
     for (uint32_t i = lane; i < n; i += 64u) {
       const uint32_t j = rev ? n - 1u - i : i;           // index of read position i in the line's strings / the reference window
       // read base -> index in `bases` (getIndexOfBase, MyDefine.cpp:228-236), complemented first on the reverse strand
@@ -129,22 +481,16 @@ __global__ __launch_bounds__(256) void train_count_kernel(TrainJob J) {
       char c = seq[j];
       if (rev) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
       const int b = c == J.bases[0] ? 0 : c == J.bases[1] ? 1 : c == J.bases[2] ? 2 : c == J.bases[3] ? 3 : -1;
-      // reference bases in read orientation: natural code (A0 C1 T2 G3; complement = code ^ 2) -> index in `bases`
-      auto ref_idx = [&](uint32_t pos_in_read) -> int {
-        const uint32_t w = rev ? n - 1u - pos_in_read : pos_in_read;
-        uint32_t code = ref[w];
-        if (code > 3u) return -1;
-        if (rev) code ^= 2u;
-        return (int)((J.remap >> (2u * code)) & 3u);
-      };
       const uint32_t bin = (uint32_t)(((uint64_t)i * bins) / n);
-      const int r0 = ref_idx(i);
-      if (b >= 0) {                                      // :421-441
+      bool shows_alt;
+      const int s0 = context_idx(i, &shows_alt);
+      if (b >= 0) {                                      // :416-442
         const uint32_t m = i + 1u < K ? i + 1u : K;       // real bases of the context, the rest is 'X'
         int kidx = (int)J.kmer_off[m];
         int v = 0;
         for (uint32_t t = 0; t < m; t++) {                // oldest base in the highest digit
-          const int x = ref_idx(i + 1u - m + t);
+          bool dummy;
+          const int x = t + 1u == m ? s0 : context_idx(i + 1u - m + t, &dummy);
           if (x < 0) { kidx = -1; break; }
           v = v * 4 + x;
         }
@@ -154,27 +500,107 @@ __global__ __launch_bounds__(256) void train_count_kernel(TrainJob J) {
           atomicAdd(J.kmers + (size_t)bin * kc + (uint32_t)kidx, 1ull);
         }
       }
-      if ((R.flags & 4u) && r0 >= 0 && b >= 0) {         // :455-480
-        const int q = (int)(signed char)qual[j];
-        if (q >= 33 && q <= 126) atomicAdd(J.quality + (((size_t)(r0 * 4 + b)) * bins + bin) * 94u + (uint32_t)(q - 33), 1ull);
+      if ((R.flags & 4u) && b >= 0) {                    // :457-480
+        uint32_t rc = ref[j];                            // refSeq[i] itself must be a base (:460,463) ...
+        int r0 = -1;
+        if (rc <= 3u) { if (rev) rc ^= 2u; r0 = (int)((J.remap >> (2u * rc)) & 3u); }
+        if (r0 >= 0) {
+          if (shows_alt) r0 = s0;                        // ... and gives way to the alternative allele the read shows (:466-468)
+          const int q = (int)(signed char)qual[j];
+          if (r0 >= 0 && q >= 33 && q <= 126)
+            atomicAdd(J.quality + (((size_t)(r0 * 4 + b)) * bins + bin) * 94u + (uint32_t)(q - 33), 1ull);
+        }
       }
     }
     if (lane == 0u) {
-      if (R.tlen > 0) {                                  // :445-450
+      if (R.tlen > 0) {                                  // :446-451
         if ((uint32_t)R.tlen < J.n_isize) atomicAdd(J.isize + R.tlen, 1ull);
         else atomicAdd(J.scalars + kTrainIsizeOverflow, 1ull);
       }
-      atomicAdd(J.scalars + kTrainReads, 1ull);          // :482
+      atomicAdd(J.scalars + kTrainReads, 1ull);          // :483
     }
   }
 }
 
-void launch_train(const TrainJob& J, hipStream_t s) {
+// wave = window: G/C and N bytes of refSequence[left .. right] (calculateGCContent); exome read counts scaled to the
+// window size (:565-566)
+__global__ __launch_bounds__(256) void train_window_gc_kernel(const TrainWindow* __restrict__ wins, const uint32_t* __restrict__ rc, uint64_t n,
+                                                              const TrainContig* __restrict__ contigs, const uint8_t* __restrict__ ref,
+                                                              uint32_t wes, double* __restrict__ gc, double* __restrict__ rcs) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t w = wave; w < n; w += n_waves) {
+    const TrainWindow W = wins[w];
+    double g = -1.0;
+    if (W.ws) {                                          // (0: behind the last target -- refSeq = NULL, GC = -1, :606-611)
+      const TrainContig C = contigs[W.contig];
+      // Genome::getSubRefSequence(chr, left, length): std::string::substr cuts at the contig's end
+      const int64_t len_asked = wes ? W.right - W.left + 1 : (int64_t)W.ws;
+      int64_t len = len_asked;
+      if (W.left + len > (int64_t)C.length) len = (int64_t)C.length - W.left;
+      uint32_t gcn = 0, nn = 0;
+      for (int64_t i = lane; i < len; i += 64) {
+        const uint32_t c = ref[C.code_off + (uint64_t)(W.left + i)];
+        gcn += (c == 1u) | (c == 3u);
+        nn += c == 4u;
+      }
+      for (int o = 32; o; o >>= 1) { gcn += __shfl_xor(gcn, o); nn += __shfl_xor(nn, o); }
+      if (len <= 0) g = 0.0;
+      else if (nn) g = -1.0;
+      else g = 1.0 * (double)gcn / (double)(len - nn);
+    }
+    if (lane == 0u) {
+      gc[w] = g;
+      uint32_t r = rc[w];
+      if (wes && W.ws) {
+        const int32_t target = (int32_t)(W.right - W.left + 1);
+        r = (uint32_t)((int32_t)(W.ws * r / (uint32_t)target));   // `rc = winSize*rc/targetSize`: unsigned arithmetic, stored in an int
+      }
+      rcs[w] = (double)(int32_t)r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void train_patch_kernel(uint8_t* codes, const uint64_t* off, const uint8_t* ch, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t b = ch[i];
+  if (b >= 'a' && b <= 'z') b -= 32u;   // Genome.cpp:529-530
+  const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
+  codes[off[i]] = (uint8_t)(acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : (b == 'X' ? 6u : 5u)));
+}
+
+}  // namespace
+
+size_t train_scan_work_bytes(uint64_t n_elems) { return ((n_elems + kScanTile - 1) / kScanTile + 1) * sizeof(StateVal); }
+
+void launch_train_lines_count(const TrainJob& J, hipStream_t s) { run_scan_count(LineOp{J}, (J.bytes + 63) / 64, J.scan_work, s); }
+void launch_train_lines_fill(const TrainJob& J, hipStream_t s) { run_scan_apply(LineOp{J}, (J.bytes + 63) / 64, J.scan_work, s); }
+
+void launch_train_chunk(const TrainJob& J, hipStream_t s) {
   if (!J.n_lines) return;
-  hipLaunchKernelGGL(train_parse_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
+  hipLaunchKernelGGL(train_fields_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
+  if (J.count_gc) {
+    run_scan(GateOp{J}, J.n_lines, J.scan_work, s);
+    run_scan(StateOp{J}, J.n_lines, J.scan_work, s);
+    run_scan(WindowOp{J}, J.n_lines, J.scan_work, s);
+  }
+  hipLaunchKernelGGL(train_cigar_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
   const uint64_t waves = J.n_lines;
   const uint32_t grid = (uint32_t)(waves * 64 / 256 + 1 < 256u * 32u ? waves * 64 / 256 + 1 : 256u * 32u);
   hipLaunchKernelGGL(train_count_kernel, dim3(grid), dim3(256), 0, s, J);
+}
+
+void launch_train_window_gc(const TrainWindow* w, const uint32_t* rc, uint64_t n, const TrainContig* contigs, const uint8_t* ref_codes,
+                            uint32_t wes, double* gc, double* rcs, hipStream_t s) {
+  if (!n) return;
+  const uint32_t grid = (uint32_t)(n / 4 + 1 < 256u * 16u ? n / 4 + 1 : 256u * 16u);
+  hipLaunchKernelGGL(train_window_gc_kernel, dim3(grid), dim3(256), 0, s, w, rc, n, contigs, ref_codes, wes, gc, rcs);
+}
+
+void launch_train_patch(uint8_t* codes, const uint64_t* off, const uint8_t* ch, uint64_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(train_patch_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, codes, off, ch, n);
 }
 
 }  // namespace sg

@@ -67,11 +67,10 @@ def test_strict_bases_flag_makes_a_literal_x_an_unknown_base(oracle_lib, tmp_pat
     assert files == sorted(os.listdir(gdir)) and files
     for f in files:
         assert open(os.path.join(odir, f), "rb").read() == open(os.path.join(gdir, f), "rb").read(), f
-    # and without the flag the X's matter: the default run differs from the strict one
-    ddir = str(tmp_path / "d")
-    ok, msg = gpu_run.run_gpu(cfg, SEED, ddir)
-    assert ok, msg
-    assert any(open(os.path.join(ddir, f), "rb").read() != open(os.path.join(gdir, f), "rb").read() for f in files)
+    # (Whether the default run differs from the strict one is a matter of the profile: the place-holder rows "Xbb" / "XXb" of
+    # the shipped profiles hold counts in the first bin only and are identity rows elsewhere (normParas, Profile.cpp:845-862),
+    # so an X in the middle of a read changes nothing a draw can show -- the oracle's own runs on the X genome and on its R
+    # twin are byte-identical.  The default reading is pinned by the byte-parity case "fasta_literal_x" above.)
 
 
 @pytest.mark.parametrize("via_cli", [False, True])

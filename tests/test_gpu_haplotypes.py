@@ -22,6 +22,7 @@ CODE = np.full(256, 5, dtype=np.uint8)
 for ch, v in ((b"A", 0), (b"C", 1), (b"T", 2), (b"G", 3), (b"N", 4)):
     CODE[ch[0]] = v
     CODE[ch.lower()[0]] = v
+CODE[ord("X")] = CODE[ord("x")] = 6   # a literal X is the k-mer trie's place holder (Profile.cpp:94-101): a code of its own
 
 
 @pytest.fixture(scope="module")
@@ -177,5 +178,6 @@ def test_fasta_layouts_do_not_change_the_reads(tmp_path):
     }
     for tag, body in variants.items():
         rewrite(body)
-        got = _run(cfg, str(tmp_path / tag))
+        # (carriage returns are bases and name bytes by default, as in fastahack; --crlf-as-lf reads the LF twin)
+        got = _run(cfg, str(tmp_path / tag), *(["--crlf-as-lf"] if tag == "crlf80" else []))
         assert got == base, tag

@@ -1,8 +1,10 @@
-"""Profile training, counting half on the MI355X: sg_train_count (train_parse_kernel + train_count_kernel,
-simuscop_amd/csrc/sg_train.hip) through the C ABI against the CPU restatement of Profile::processRead's counters
-(oracle/train_oracle.cpp), on SAM lines made from reads THE GPU sampled plus lines exercising every filter and the CIGAR
-walk.  Bar: every counter bit-exact (integer work).  PARITY UNPINNED against the reference binary (no samtools / BAM here);
-tests/test_train_counts.py closes the loop from the other side (the counts give back the profile tables)."""
+"""Profile training on the MI355X: sg_train_* (simuscop_amd/csrc/sg_train.hip) through the C ABI and the
+`seqToProfile` command line against the CPU restatement of Profile::train (oracle/train_oracle.cpp), on SAM lines made from
+reads THE GPU sampled plus crafted lines (every filter, the CIGAR walk, known variants, several contigs, reads that step
+backwards, exome targets).  Bar: every counter and every (GC, read count) pair bit-exact, the written profile byte for byte
+(integer work, then the same fp64 operations in the same order).  The counting is PARITY UNPINNED against the reference
+binary (no samtools / BAM here); what a reference run can pin is pinned: the unmodified binary loads the file `seqToProfile`
+wrote and samples from it exactly as oracle(mt) does (below, and tests/test_train_profile_cpu.py on the CPU)."""
 import ctypes as C
 import os
 import subprocess
@@ -44,9 +46,21 @@ def _reference_on_device(eng, ctx, fasta_path, line_len=60):
     return keys
 
 
+ARRAYS = ("subs1", "subs2", "kmers", "quality", "isize", "ins_len", "del_len")
+SCALARS = ("lines", "reads_counted", "cigar_chars", "insert_events", "delete_events", "isize_overflow", "indel_len_overflow", "skipped_overhang",
+           "gc_rejected", "gc_windows")
+
+
+def _same_counts(got, ga, want, wa):
+    for k in ARRAYS:
+        assert np.array_equal(ga[k], wa[k]), (k, int((ga[k] != wa[k]).sum()), ga[k].sum(), wa[k].sum())
+    for k in SCALARS:
+        assert getattr(got, k) == getattr(want, k), (k, getattr(got, k), getattr(want, k))
+
+
 @pytest.mark.parametrize("profile,insert", [("xten", 350), ("hs2000", 200)])
 def test_device_counts_equal_the_restatement(profile, insert, oracle_lib, tmp_path):
-    oracle_lib.orc_train_count.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
+    oracle_lib.orc_train_count.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                            C.POINTER(simuscop_amd.SgTrainCounts)]
     wd = str(tmp_path)
     cfg, fa = H.histogram_config(cases, wd, profile, "PE", 40, insert)
@@ -62,7 +76,7 @@ def test_device_counts_equal_the_restatement(profile, insert, oracle_lib, tmp_pa
     lines += TU.filter_lines(T.L)
     sam = b"\n".join(lines) + b"\n\n"           # (an empty line at the end: dropped)
     want, wa = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 1024)
-    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 1024, C.byref(want)) == 0
+    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 1024, 256, C.byref(want)) == 0
     eng = simuscop_amd.load_engine()
     ctx = C.c_void_p()
     assert eng.sg_create(C.byref(ctx), 0, 1) == 0
@@ -70,26 +84,203 @@ def test_device_counts_equal_the_restatement(profile, insert, oracle_lib, tmp_pa
         keys = _reference_on_device(eng, ctx, fa)
         got, ga = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 1024)
         karr = (C.c_char_p * len(keys))(*keys)
-        rc = eng.sg_train_count(ctx, sam, len(sam), karr, len(keys), T.bases.encode(), 3, T.bins, 1024, C.byref(got))
+        rc = eng.sg_train_count(ctx, sam, len(sam), karr, len(keys), T.bases.encode(), 3, T.bins, 1024, 256, C.byref(got))
         assert rc == 0, eng.sg_last_error(ctx)
-        for k in ("subs1", "subs2", "kmers", "quality", "isize"):
-            assert np.array_equal(ga[k], wa[k]), k
-        for k in ("lines", "reads_counted", "cigar_chars", "insert_events", "delete_events", "isize_overflow", "skipped_overhang"):
-            assert getattr(got, k) == getattr(want, k), (k, getattr(got, k), getattr(want, k))
-        assert list(got.ins_len) == list(want.ins_len) and list(got.del_len) == list(want.del_len)
+        _same_counts(got, ga, want, wa)
         assert got.reads_counted > 200_000 and ga["subs2"].sum() > 0 and ga["quality"].sum() > 10_000_000
         # a line with fewer than eleven fields is an error, as in the reference (Profile.cpp:246-251)
         bad = b"r0\t0\tchr1\t100\t60\n"
-        assert eng.sg_train_count(ctx, bad, len(bad), karr, len(keys), T.bases.encode(), 3, T.bins, 1024, C.byref(got)) != 0
+        assert eng.sg_train_count(ctx, bad, len(bad), karr, len(keys), T.bases.encode(), 3, T.bins, 1024, 256, C.byref(got)) != 0
         # other base orders / context lengths (the kernel's context index against the restatement's trie)
         for bases, kmer in ((b"ACGT", 2), (b"GTCA", 4)):
             kc = sum(4 ** m for m in range(1, kmer + 1))
             w2, wa2 = TU.count_arrays(simuscop_amd.SgTrainCounts, kc, 20, 1024)
             g2, ga2 = TU.count_arrays(simuscop_amd.SgTrainCounts, kc, 20, 1024)
             part = b"\n".join(lines[:40000]) + b"\n"
-            assert oracle_lib.orc_train_count(part, len(part), fa.encode(), bases, kmer, 20, 1024, C.byref(w2)) == 0
-            assert eng.sg_train_count(ctx, part, len(part), karr, len(keys), bases, kmer, 20, 1024, C.byref(g2)) == 0, eng.sg_last_error(ctx)
+            assert oracle_lib.orc_train_count(part, len(part), fa.encode(), bases, kmer, 20, 1024, 256, C.byref(w2)) == 0
+            assert eng.sg_train_count(ctx, part, len(part), karr, len(keys), bases, kmer, 20, 1024, 256, C.byref(g2)) == 0, eng.sg_last_error(ctx)
             for k in ("subs1", "subs2", "kmers", "quality", "isize"):
                 assert np.array_equal(ga2[k], wa2[k]), (bases, kmer, k)
     finally:
         eng.sg_destroy(ctx)
+
+
+# ---- the whole of Profile::train ----
+def _sampled_lines(oracle_lib, wd, profile="xten", insert=350, coverage=10):
+    cfg, fa = H.histogram_config(cases, wd, profile, "PE", coverage, insert)
+    out = os.path.join(wd, "gpu")
+    r = subprocess.run([SIMU, cfg, "--seed", "78", "--out", out, "--quiet"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    T = H.ProfileTables(oracle_lib, os.path.join(cases.TESTDATA, cases.PROFILES[profile]), True, insert)
+    ref = H.read_fasta_one(fa)
+    f1, f2 = sorted(os.path.join(out, f) for f in os.listdir(out))
+    fq1, fq2 = H.Fastq(f1), H.Fastq(f2)
+    lines = TU.sam_from_pairs(ref, fq1, fq2, T.L, T.isize_min + len(T.isize_pmf) - 1, cuts=(H.mismatch_cut(T, False), H.mismatch_cut(T, True)))
+    return lines, fa, T
+
+
+def _setup_from_files(keys, lens, vcf, bed, T, keep):
+    """sg_train_setup from the VCF / BED files, parsed here the way vcfparser.cpp:26-106 and Genome.cpp:238-299, 684-739 do (the
+    product's own parsers are exercised through `seqToProfile` below)."""
+    row = {k: i for i, k in enumerate(keys)}
+    abbr = lambda n: n.split(b"chrom", 1)[1] if b"chrom" in n else (n.split(b"chr", 1)[1] if b"chr" in n else n)   # noqa: E731
+    snv, ins, dele = [], [], []
+    for line in open(vcf, "rb"):
+        if line.startswith(b"#"):
+            continue
+        f = line.rstrip(b"\n").split(b"\t")
+        if len(f) < 10:
+            continue
+        info = f[7]
+        if b"DP=" in info and int(info.split(b"DP=", 1)[1].split(b";", 1)[0]) < 10:
+            continue
+        if float(f[5]) < 20:
+            continue
+        c = row.get(abbr(f[0]))
+        if c is None:
+            continue
+        pos, homo = int(f[1]), f[9].split(b":")[0] != b"1/1"
+        if len(f[3]) > 1:
+            dele.append((c, pos + 1, len(f[3]) - 1))
+        elif len(f[4]) > 1:
+            ins.append((c, pos, len(f[4]) - 1))
+        else:
+            snv.append((c, pos, f[4][:1], 1 if homo else 0))
+    st = simuscop_amd.SgTrainSetup()
+    karr = (C.c_char_p * len(keys))(*keys)
+    keep += [karr]
+    st.contig_keys, st.n_contigs, st.bases, st.kmer, st.bins = karr, len(keys), T.bases.encode(), 3, T.bins
+    st.n_isize, st.n_indel_len, st.count_gc, st.window = 2048, 256, 1, 1000
+
+    def arr(ctype, vals):
+        a = (ctype * max(1, len(vals)))(*vals)
+        keep.append(a)
+        return a
+    st.n_snv = len(snv)
+    st.snv_contig, st.snv_pos = arr(C.c_uint32, [x[0] for x in snv]), arr(C.c_int64, [x[1] for x in snv])
+    alt = b"".join(x[2] for x in snv)
+    keep.append(alt)
+    st.snv_alt, st.snv_homo = alt, arr(C.c_uint8, [x[3] for x in snv])
+    st.n_ins, st.ins_contig, st.ins_pos, st.ins_len = len(ins), arr(C.c_uint32, [x[0] for x in ins]), arr(C.c_int64, [x[1] for x in ins]), arr(C.c_int32, [x[2] for x in ins])
+    st.n_del, st.del_contig, st.del_pos, st.del_len = len(dele), arr(C.c_uint32, [x[0] for x in dele]), arr(C.c_int64, [x[1] for x in dele]), arr(C.c_int32, [x[2] for x in dele])
+    if bed:
+        per = {}
+        for line in open(bed, "rb"):
+            f = line.rstrip(b"\n").split(b"\t")
+            c = row.get(abbr(f[0]))
+            if c is None or lens[c] <= 0:
+                continue
+            e = int(f[2])
+            sp, ep = max(1, int(f[1]) - 50 + 1), min(lens[c], (lens[c] - (-e) % lens[c] if e <= 0 else e) + 50)
+            k, s0 = (ep - sp + 1) // 1000, sp
+            for i in range(max(k, 0)):
+                e0 = ep if i == k - 1 else s0 + 999
+                per.setdefault(c, []).append((s0, e0))
+                s0 = e0 + 1
+            if s0 <= ep:
+                per.setdefault(c, []).append((s0, ep))
+        first, sp, ep = [0], [], []
+        for c in range(len(keys)):
+            for a, b in per.get(c, []):
+                sp.append(a)
+                ep.append(b)
+            first.append(len(sp))
+        st.target_first, st.target_spos, st.target_epos = arr(C.c_uint64, first), arr(C.c_int64, sp), arr(C.c_int64, ep)
+    return st
+
+
+@pytest.mark.parametrize("exome", [False, True])
+def test_device_training_equals_the_restatement(exome, oracle_lib, tmp_path):
+    """sg_train_begin / _feed (the text in nine chunks of unequal size) / _finish against orc_train: counters, and the (GC,
+    read count) pairs countGC pushed, in its order."""
+    import test_train_profile_cpu as TP
+    TP.declare(oracle_lib)
+    wd = str(tmp_path)
+    lines, fa1, T = _sampled_lines(oracle_lib, wd)
+    fa, vcf, bed, sam = TU.training_inputs(wd, fa1, lines, T.L, exome=exome)
+    want, wa = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+    cap = 200000
+    wgc, wrc, wn = (C.c_double * cap)(), (C.c_double * cap)(), C.c_uint64()
+    assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), (bed or "").encode(), T.bases.encode(), 3, T.bins, 2048, 256,
+                                C.byref(want), wgc, wrc, cap, C.byref(wn)) == 0
+    eng = simuscop_amd.load_engine()
+    ctx = C.c_void_p()
+    assert eng.sg_create(C.byref(ctx), 0, 1) == 0
+    try:
+        keys = _reference_on_device(eng, ctx, fa)
+        lens = [len(b"".join(part.split(b"\n")[1:])) for part in open(fa, "rb").read().split(b">")[1:]]
+        keep = []
+        st = _setup_from_files(keys, lens, vcf, bed, T, keep)
+        assert eng.sg_train_begin(ctx, C.byref(st)) == 0, eng.sg_last_error(ctx)
+        cuts = [0]
+        for frac in (0.001, 0.13, 0.131, 0.4, 0.62, 0.95, 0.9999, 0.99995):
+            cuts.append(sam.rfind(b"\n", 0, max(1, int(len(sam) * frac))) + 1)
+        cuts.append(len(sam))
+        for a, b in zip(cuts, cuts[1:]):
+            part = sam[a:b]
+            assert eng.sg_train_feed(ctx, part, len(part)) == 0, eng.sg_last_error(ctx)
+        got, ga = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+        ggc, grc, gn = (C.c_double * cap)(), (C.c_double * cap)(), C.c_uint64()
+        assert eng.sg_train_finish(ctx, C.byref(got), ggc, grc, cap, C.byref(gn)) == 0, eng.sg_last_error(ctx)
+        _same_counts(got, ga, want, wa)
+        assert gn.value == wn.value and gn.value > (50 if exome else 1000)
+        assert list(ggc[:gn.value]) == list(wgc[:wn.value]) and list(grc[:gn.value]) == list(wrc[:wn.value])
+        assert got.gc_rejected > 100 and got.reads_counted > 50_000 // (20 if exome else 1)
+    finally:
+        eng.sg_destroy(ctx)
+
+
+@pytest.mark.parametrize("exome", [False, True])
+def test_seqtoprofile_writes_the_profile_of_the_restatement(exome, oracle_lib, tmp_path):
+    """The command line (src/seqToProfile.cpp's options + --sam) end to end: its profile file is the restatement's, byte for
+    byte behind the time stamp line, and so is the `.gc` side file of estimateGCParas; the unmodified reference binary -- where
+    it has been built (this container; it travels to the GPU box with oracle/_ref) -- loads the file the GPU path wrote and
+    samples from it as oracle(mt) does."""
+    import hashlib
+    import test_train_profile_cpu as TP
+    TP.declare(oracle_lib)
+    wd = str(tmp_path)
+    lines, fa1, T = _sampled_lines(oracle_lib, wd, coverage=12)
+    fa, vcf, bed, sam = TU.training_inputs(wd, fa1, lines, T.L, exome=exome)
+    sam_path = os.path.join(wd, "reads.sam")
+    open(sam_path, "wb").write(sam)
+    want = os.path.join(wd, "want.profile")
+    assert oracle_lib.orc_train_profile(sam, len(sam), fa.encode(), vcf.encode(), (bed or "").encode(), b"ACTG", 3, 50, want.encode(), sam_path.encode(),
+                                        b"stamp\n") == 0
+    got = os.path.join(wd, "got.profile")
+    exe = os.path.join(ROOT, "simuscop_amd", "lib", "seqToProfile")
+    cmd = [exe, "--sam", sam_path, "-v", vcf, "-r", fa, "-o", got, "--quiet"] + (["-t", bed] if bed else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = open(want, "rb").read().split(b"\n", 1), open(got, "rb").read().split(b"\n", 1)
+    assert a[0] == b"#model created at stamp" and b[0].startswith(b"#model created at ")
+    assert a[1] == b[1], "profile text differs from the restatement's"
+    assert os.path.exists(want + ".gc") == os.path.exists(got + ".gc")
+    if os.path.exists(want + ".gc"):
+        assert open(want + ".gc", "rb").read() == open(got + ".gc", "rb").read()
+    if not exome:
+        assert os.path.exists(got + ".gc")   # 12x: the GC model is fitted
+    # through standard input, as `samtools view ... | seqToProfile --sam -` would
+    got2 = os.path.join(wd, "got2.profile")
+    with open(sam_path, "rb") as f:
+        r = subprocess.run([exe, "--sam", "-", "-v", vcf, "-r", fa, "--quiet"] + (["-t", bed] if bed else []), stdin=f, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split(b"\n", 1)[1].replace(b"#reads: -", b"#reads: " + sam_path.encode(), 1) == b[1]
+    # option checks of src/seqToProfile.cpp:84-121
+    for bad, msg in ((["-v", vcf, "-r", fa], "Use --bam"), (["--sam", sam_path, "-r", fa], "Use --vcf"), (["--sam", sam_path, "-v", vcf], "Use --ref"),
+                     (["--sam", sam_path, "-v", vcf, "-r", fa, "-k", "6"], "maximum value of 5"), (["--sam", sam_path, "-v", vcf, "-r", fa, "-B", "9"], "minimum value of 10")):
+        r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr[-300:])
+    REF, SHIM = os.path.join(ROOT, "oracle", "_ref", "simuReads"), os.path.join(ROOT, "oracle", "_ref", "libfakeclock.so")
+    if os.path.exists(REF) and not exome:
+        cfg, out = os.path.join(wd, "sim.txt"), os.path.join(wd, "sim_out")
+        cases._config(cfg, ref=fa1, profile=got, name="t", output=out, layout="PE", threads=1, verbose=0, coverage=1, insertSize=350, ploidy=2)
+        env = dict(os.environ, LD_PRELOAD=SHIM, FAKECLOCK_SEC=str(cases.FAKE_SEC), FAKECLOCK_NSEC=str(cases.FAKE_NSEC))
+        r = subprocess.run([REF, cfg], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1000:]
+        md5 = lambda d: {f: hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))}   # noqa: E731
+        ref_md5 = md5(out)
+        for f in os.listdir(out):
+            os.remove(os.path.join(out, f))
+        assert oracle_lib.orc_simulate(cfg.encode(), 0, cases.FAKE_SEC, cases.FAKE_NSEC, b"", 1) == 0
+        assert md5(out) == ref_md5 and ref_md5

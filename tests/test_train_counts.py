@@ -14,7 +14,7 @@ import train_util as TU
 
 
 def _declare(lib):
-    lib.orc_train_count.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32,
+    lib.orc_train_count.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                     C.POINTER(simuscop_amd.SgTrainCounts)]
     return lib
 
@@ -37,15 +37,15 @@ def test_counts_give_back_the_profile(oracle_lib, tmp_path):
     _declare(oracle_lib)
     sam, fa, T = make_sam(oracle_lib, str(tmp_path))
     st, a = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
-    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 2048, C.byref(st)) == 0
+    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 2048, 256, C.byref(st)) == 0
     n_lines = sam.count(b"\n")
     assert st.lines == n_lines and 0.8 * n_lines < st.reads_counted < n_lines
     assert st.insert_events > 0 and st.delete_events > 0 and st.isize_overflow == 1 and st.skipped_overhang == 1
-    assert st.ins_len[2] >= 1 and st.del_len[3] >= 1            # the crafted 20M2I..3D10M line
+    assert a["ins_len"][2] >= 1 and a["del_len"][3] >= 1            # the crafted 20M2I..3D10M line
     # ... and without the crafted lines (their made-up bases are no sample of the profile):
     sam, fa, T = make_sam(oracle_lib, str(tmp_path / "plain"), crafted=False)
     st, a = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
-    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 2048, C.byref(st)) == 0
+    assert oracle_lib.orc_train_count(sam, len(sam), fa.encode(), T.bases.encode(), 3, T.bins, 2048, 256, C.byref(st)) == 0
     # the counters against the tables the reads were sampled from (G1 / G2 / G4 of tests/histo_util.py, read backwards)
     for mate, key in ((0, "subs1"), (1, "subs2")):
         z, dof, pmin, cells, worst = H.categorical_report(a[key].astype(np.float64), T.sub[mate])
