@@ -26,6 +26,8 @@
 //     zero-initialised here.  `gcs[i]*bins` reaches `bins` itself for a window of G/C only (:720,738: one element past
 //     the arrays): the arrays have bins + 1 cells.  `counts[i]/expectCount` divides by zero with fewer than 50 windows
 //     (:723-726): the step is 1 then.  The median of no windows (:1473) is 0.
+//     With no GC percent holding more than 20 windows the tails are extrapolated from gcMeans[-1] (:815-820): all means
+//     stay 0 then.
 //   * normParas(false) reads iSizeDist past its row when five times the most frequent insert size exceeds the largest
 //     one seen (:884-889): columns past the row count as 0.
 //   * SNVs outside their contig (written past the string, Genome.cpp:471-474) are skipped.
@@ -614,8 +616,10 @@ struct TrainState : Trainer {
         gcMeans[k] = 0;
       }
     }
-    for (int k = 0; k < minGC; k++) gcMeans[k] = gcMeans[minGC] * k / minGC;
-    for (int k = maxGC + 1; k <= 100; k++) gcMeans[k] = gcMeans[maxGC] - gcMeans[maxGC] * (k - maxGC) / (100 - maxGC);
+    if (minGC >= 0) {   // (no GC percent with more than 20 windows: the reference reads gcMeans[-1] here; all means stay 0)
+      for (int k = 0; k < minGC; k++) gcMeans[k] = gcMeans[minGC] * k / minGC;
+      for (int k = maxGC + 1; k <= 100; k++) gcMeans[k] = gcMeans[maxGC] - gcMeans[maxGC] * (k - maxGC) / (100 - maxGC);
+    }
     gcStd = 0;
     for (int j : indxs) {
       const int k = (int)(gcs[j] * 100);

@@ -254,9 +254,9 @@ double median_of(std::vector<double> v) {   // lib/mydefine/MyDefine.h:72-104; n
 }
 
 // Profile::estimateGCParas (Profile.cpp:713-834): thin the windows to ~150,000, normalise the read counts by their median,
-// fit a locally weighted line at every GC percent.  Three places where the reference reads memory it does not own are
+// fit a locally weighted line at every GC percent.  Four places where the reference reads memory it does not own are
 // given a meaning here: the thinning counters start at zero, a window of G/C only has a cell of its
-// own, fewer than 50 windows thin nothing.
+// own, fewer than 50 windows thin nothing, and without any fitted percent no tail is extrapolated.
 void fit_gc_model(Model& M, const std::string& gc_file) {
   const int B = 50;
   std::vector<int> per_bin(B + 1, 0), step(B + 1, 1), seen(B + 1, 0);
@@ -333,8 +333,10 @@ void fit_gc_model(Model& M, const std::string& gc_file) {
     y += at * b1;
     M.gc_means[k] = std::max(0.0, clamp0(y));
   }
-  for (int k = 0; k < lo; k++) M.gc_means[k] = M.gc_means[lo] * k / lo;
-  for (int k = hi + 1; k <= 100; k++) M.gc_means[k] = M.gc_means[hi] - M.gc_means[hi] * (k - hi) / (100 - hi);
+  if (lo >= 0) {   // (no percent with more than 20 windows -- an exome with few targets: every mean stays 0)
+    for (int k = 0; k < lo; k++) M.gc_means[k] = M.gc_means[lo] * k / lo;
+    for (int k = hi + 1; k <= 100; k++) M.gc_means[k] = M.gc_means[hi] - M.gc_means[hi] * (k - hi) / (100 - hi);
+  }
   double ss = 0;
   for (int j : kept) ss += std::pow(M.rcs[j] - M.gc_means[(int)(M.gcs[j] * 100)], 2);
   M.gc_std = std::sqrt(ss / kept.size());

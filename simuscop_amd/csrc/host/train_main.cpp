@@ -2,7 +2,7 @@
 // same options, same checks, same exit codes) over the GPU path of host/train.cpp.
 // Additive options the reference would reject:
 //   --sam <file|->   lines of `samtools view -F 0xD04 -q 20` text from a file or standard input (instead of running samtools)
-//   --device <n>     GPU to use (default 0)        --quiet   no progress lines
+//   --device <n>     GPU to use (default 0)        --quiet   no progress lines        --stats   one JSON line of counts and times
 #include <getopt.h>
 
 #include <cstdio>
@@ -37,11 +37,12 @@ int main(int argc, char* argv[]) {
   simu_train_options o;
   simu_train_default_options(&o);
   std::string bam, sam, target, vcf, ref, out, samtools;
+  bool stats = false;
   const struct option long_options[] = {
       {"help", no_argument, 0, 'h'},        {"bam", required_argument, 0, 'b'},    {"target", required_argument, 0, 't'},
       {"vcf", required_argument, 0, 'v'},   {"ref", required_argument, 0, 'r'},    {"output", required_argument, 0, 'o'},
       {"samtools", required_argument, 0, 's'}, {"kmer", required_argument, 0, 'k'}, {"bins", required_argument, 0, 'B'},
-      {"sam", required_argument, 0, 1000},  {"device", required_argument, 0, 1001}, {"quiet", no_argument, 0, 1002},
+      {"sam", required_argument, 0, 1000},  {"device", required_argument, 0, 1001}, {"quiet", no_argument, 0, 1002},   {"stats", no_argument, 0, 1003},
       {0, 0, 0, 0}};
   int c;
   while ((c = getopt_long(argc, argv, "hb:t:v:r:o:s:k:B:", long_options, NULL)) != -1) {
@@ -58,6 +59,7 @@ int main(int argc, char* argv[]) {
       case 1000: sam = optarg; break;
       case 1001: o.device = atoi(optarg); break;
       case 1002: o.quiet = 1; break;
+      case 1003: stats = true; break;
       default: usage(argv[0]); return 1;
     }
   }
@@ -97,6 +99,12 @@ int main(int argc, char* argv[]) {
     if (err[0]) std::cerr << err << std::endl;
     return rc;
   }
+  if (stats)
+    fprintf(stderr, "{\"lines\": %llu, \"reads_counted\": %llu, \"gc_rejected\": %llu, \"gc_windows\": %llu, \"gc_pairs\": %llu, \"skipped_overhang\": %llu, "
+                    "\"sam_bytes\": %llu, \"read_length\": %d, \"bins\": %d, \"gc_fitted\": %d, \"t_reference\": %.4f, \"t_reads\": %.4f, \"t_total\": %.4f}\n",
+            (unsigned long long)st.lines, (unsigned long long)st.reads_counted, (unsigned long long)st.gc_rejected, (unsigned long long)st.gc_windows,
+            (unsigned long long)st.gc_pairs, (unsigned long long)st.skipped_overhang, (unsigned long long)st.sam_bytes, st.read_length, st.bins, st.gc_fitted,
+            st.t_reference, st.t_reads, st.t_total);
   if (!o.quiet) {
     const long secs = (long)st.t_total;
     std::cerr << "\nElapsed time: " << secs / 60 << " minutes and " << secs % 60 << " seconds!\n" << std::endl;

@@ -79,17 +79,22 @@ namespace {
 // device.  A whole-genome run allocates ~60 GB in a few dozen blocks and returns them at its end; the next run of the
 // process asked the runtime for the same blocks again, and every dozen runs or so ONE such hipMalloc took 2-5 s
 // (`SG_TRACE_ALLOC=1 python tools/c3_steps.py`: "hipMalloc 3455.3 MB: 4925.76 ms" in the thirteenth run, 20-40 ms in the
-// others) -- seventeen times the run itself.  Best fit within 1.5x; the cache holds at most SG_BLOCK_CACHE_GB (default
-// 160) and gives everything back through sg_release_cached_memory().  SG_BLOCK_CACHE_GB=0 turns it off.
+// others) -- seventeen times the run itself.  Best fit within 1.5x; the cache holds at most SG_BLOCK_CACHE_GB (default: a
+// third of the device's memory) and gives everything back through sg_release_cached_memory().  SG_BLOCK_CACHE_GB=0 turns it off.
 struct BlockCache {
   struct Block { void* p; size_t cap; int dev; };
   std::mutex mu;
   std::vector<Block> blocks;   // oldest first
   size_t held = 0;
+  // Default: a third of the device's memory (MI355X: 96 GB -- a whole-genome run's ~60 GB of blocks fit; what other
+  // allocators of the process and other processes on the device may need stays free), SG_BLOCK_CACHE_GB overrides.
   static size_t limit() {
     static const size_t v = [] {
       const char* e = getenv("SG_BLOCK_CACHE_GB");
-      return (size_t)((e ? atof(e) : 160.0) * 1073741824.0);
+      if (e) return (size_t)(atof(e) * 1073741824.0);
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) return (size_t)(64.0 * 1073741824.0);
+      return total_b / 3;
     }();
     return v;
   }
@@ -1133,7 +1138,7 @@ int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, u
   if (out->ins_len) memcpy(out->ins_len, is + T->n_isize, (size_t)T->n_indel_len * 8);
   if (out->del_len) memcpy(out->del_len, is + T->n_isize + T->n_indel_len, (size_t)T->n_indel_len * 8);
   const uint64_t* sc = is + T->n_isize + 2 * (size_t)T->n_indel_len;
-  out->lines = T->lines;
+  out->lines = T->lines - sc[sg::kTrainEmptyLines];   // (empty lines are no reads: Profile.cpp:229-231)
   out->reads_counted = sc[sg::kTrainReads];
   out->cigar_chars = sc[sg::kTrainCigarChars];
   out->insert_events = sc[sg::kTrainInsEvents];
@@ -1826,7 +1831,12 @@ void sg_release_cached_memory(void) {
 
 int sg_host_free(sg_ctx* ctx, void* host_ptr) {
   if (!ctx) return SG_ERR_INVALID;
-  if (host_ptr && !host_cache().give(host_ptr)) SG_HIP(hipHostFree(host_ptr));
+  if (!host_ptr) return SG_OK;
+  // hipHostFree waits for the device; a buffer that goes to the cache instead may be handed out again at once, so copies
+  // still reading or writing it (sg_reference_chunk's asynchronous uploads on an error path) must have ended
+  SG_HIP(hipSetDevice(ctx->device));
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  if (!host_cache().give(host_ptr)) SG_HIP(hipHostFree(host_ptr));
   return SG_OK;
 }
 

@@ -8,7 +8,7 @@ namespace sg {
 constexpr uint32_t kTrainKeyBytes = 64;  // contig key slots (NUL terminated)
 // single counters behind the count tables (u64 each)
 enum : uint32_t { kTrainReads = 0, kTrainCigarChars, kTrainInsEvents, kTrainDelEvents, kTrainIsizeOverflow, kTrainOverhang,
-                  kTrainIndelLenOverflow, kTrainGcRejected, kTrainScalars };
+                  kTrainIndelLenOverflow, kTrainGcRejected, kTrainEmptyLines, kTrainScalars };
 
 struct TrainContig {
   uint64_t code_off, length;

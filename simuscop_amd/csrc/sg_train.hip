@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void train_fields_kernel(TrainJob J) {
   const char* p = J.text + (li ? J.line_end[li - 1] + 1 : 0);
   const char* le = J.text + J.line_end[li];  // the line break
   auto done = [&]() { J.reads[li] = R; };
-  if (p == le) { done(); return; }           // an empty line: processRead returns at once (:229-231)
+  if (p == le) { atomicAdd(J.scalars + kTrainEmptyLines, 1ull); done(); return; }   // an empty line: processRead returns at once (:229-231)
   // ---- the first eleven fields (:244-251) ----
   const char* fb[11];
   const char* fe[11];
