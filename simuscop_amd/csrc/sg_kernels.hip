@@ -1348,10 +1348,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
   // L2: WRITE_SIZE 6.43 -> see profiles/r03_final.)
   const bool tail_whole = ((uint32_t)P.L & 7u) == 7u && ((uint32_t)P.L + 7u) / 8u == TI;
   const uint32_t TIp = tail_whole ? TI : TI - 1u;
-  // 16-base UNITS per plain read (the plain16 steps below): unit u = items 2u and 2u + 1.  An odd item count leaves the last
-  // unit with one item (L = 151: 19 items, nine pairs and the seven-base tail on its own); a whole last item of seven bases
-  // (tail_whole) carries the line break and the "+" line wherever it falls (L = 303: item 37, the second half of unit 18).
-  const uint32_t TI16 = (TIp + 1u) >> 1;
+  // 16-base items per plain read (the plain16 steps below).  A whole last item of seven bases (tail_whole) carries the line
+  // break and the "+" line and only the 8-base steps write those: it stays out of the pairs (L = 303: 38 items, 18 pairs +
+  // items 36 and 37 on their own; found by fuzz seeds 222 / 224, whose 303-base reads lost their line break to a sixteenth base)
+  const uint32_t TI16 = (tail_whole ? TIp - 1u : TIp) >> 1;
   const uint32_t inv_TI16 = TI16 ? (1u << 20) / TI16 + 1u : 0u;   // ceil-reciprocal (i / TI16 exact while i * TI16 < 2^20)
 
   // Lane -> (read, item) map over the first TI = ceil(L / 8) items of a group's G = 63 reads: their items form one
@@ -1689,16 +1689,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     }
     const uint32_t n_items = n_fast * TI, n_stream = n_items + n_ovf;
     const uint32_t nmain = (dg & 256u) ? 0u : (n_stream + 63u) / 64u;   // (ablations: no general / no plain steps)
-    // The plain reads' items walk the PLAIN16 steps (round 4): lane = one unit of SIXTEEN bases, items 2c and 2c + 1 of one
-    // read -- one map, one row fetch, one 8-byte window of the 2-bit copy (21 codes = 42 bits), two 16-byte stores for what
-    // were two of each.  A read's units are neighbours in the stream, its last unit may hold one item only (the second half
-    // idles: one half in twenty at 151 bases), so a read's text leaves in ONE instalment, lane after lane.  (First form of
-    // the round: whole steps of pairs, the odd items and the last step's pairs through 8-base steps of their own afterwards --
-    // 4.6 % fewer instructions, no faster: every read's last bytes left nine steps after their neighbours, when the line had
-    // gone from L2, WRITE_SIZE 5.80 -> 6.99 M KiB per launch; profiles/r04_start.)  SG_FDIAG 512 keeps the 8-base steps.
-    const uint32_t n_p16 = (dg & 512u) ? 0u : n_plain * TI16;
-    const uint32_t np16steps = (dg & 128u) ? 0u : (n_p16 + 63u) >> 6;
-    const uint32_t n_pitems = (dg & 512u) ? n_plain * TIp : 0u, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
+    // The plain reads' items walk two loops (round 4).  PLAIN16 steps: lane = SIXTEEN bases, items 2c and 2c + 1 of one read
+    // -- one map, one row fetch, one 8-byte window of the 2-bit copy (21 codes = 42 bits), two 16-byte stores for what were
+    // two of each; only WHOLE steps run that way.  What is left -- the 16-base items of the last, partial step, as their two
+    // halves, and the reads' odd last 8-base item (cnt8 = TIp mod 2) -- goes through the 8-base plain steps as one stream,
+    // so that neither loop ends in a step with idle lanes of its own.
+    const uint32_t n_p16 = (dg & 512u) ? 0u : n_plain * TI16;      // (SG_FDIAG 512: no 16-base steps)
+    const uint32_t np16steps = (dg & 128u) ? 0u : n_p16 >> 6, rem16 = n_p16 - (np16steps << 6);
+    const uint32_t cnt8 = (dg & 512u) ? TIp : TIp - 2u * TI16, c8_base = (dg & 512u) ? 0u : 2u * TI16;
+    const uint32_t n_pitems = 2u * rem16 + n_plain * cnt8, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
     // AHEAD (the chain LDS -> LDS -> L2 is ~1000 cycles; issued before the previous step's sampling it is covered by it).
@@ -1771,16 +1770,22 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
         nfix += (uint32_t)__popcll(fm);
       }
     };
-    // ---- plain16 steps: lane = unit (two items; the last unit of a read may hold one) ----
-    if (np16steps) {
-      struct P16 { uint32_t r, c, src, out; bool ok; uint2 w; };
-      uint32_t TI16_v = TI16, inv_TI16_v = inv_TI16, qual_at = (uint32_t)P.L + 3u, TIp_v = TIp;
-      asm volatile("" : "+v"(TI16_v), "+v"(inv_TI16_v), "+v"(qual_at), "+v"(TIp_v));   // (as scalars they were spilled, see the 8-base loop)
+    // The odd items leave in the MIDDLE of their reads' pairs (round 4): a read's last bytes written nine steps behind its
+    // pairs met the line gone from L2 (WRITE_SIZE 5.80 -> 6.99 M KiB per launch, profiles/r04_start); with the singles' step
+    // between the two halves of the 16-base steps no instalment of a read is more than ~four steps from the other.
+    const uint32_t h16 = np16steps >> 1, s8_first = (cnt8 && npsteps) ? 1u : 0u;
+#pragma unroll 1
+    for (uint32_t ph = 0; ph < 2u; ph++) {
+    const uint32_t a16 = ph ? h16 : 0u, b16 = ph ? np16steps : h16;
+    const uint32_t a8 = ph ? s8_first : 0u, b8 = ph ? npsteps : s8_first;
+    // ---- plain16 steps: whole steps of 16-base items ----
+    if (a16 < b16) {
+      struct P16 { uint32_t r, c, src, out; uint2 w; };
+      uint32_t TI16_v = TI16, inv_TI16_v = inv_TI16, qual_at = (uint32_t)P.L + 3u;
+      asm volatile("" : "+v"(TI16_v), "+v"(inv_TI16_v), "+v"(qual_at));   // (as scalars they were spilled, see the 8-base loop)
       auto fetch16 = [&](uint32_t step) -> P16 {
         P16 st;
-        const uint32_t i_raw = step * 64u + lane;
-        st.ok = i_raw < n_p16;
-        const uint32_t i = min(i_raw, n_p16 - 1u);             // idle lanes redo the stream's last unit, their stores are dropped
+        const uint32_t i = step * 64u + lane;                  // < n_p16: whole steps only, every lane has an item
         const uint32_t ri = __umul24(i, inv_TI16_v) >> 20;    // i / TI16
         st.c = i - __umul24(ri, TI16_v);
         st.r = permp[ri];
@@ -1795,21 +1800,17 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
       const uint32_t c3b = dev_ctx(KIND_BASE, m, B.batch_id);
       const uint32_t lgW = P.lgW;
       auto run16 = [&](const P16& st) {
-        const uint32_t c8 = 2u * st.c;   // the lane's two 8-base items: c8, c8 + 1 (the second may lie behind the read's last)
-        const bool two = c8 + 1u < TIp_v;
+        const uint32_t c8 = 2u * st.c;   // the lane's two 8-base items: c8, c8 + 1
         // 21 source codes (positions 16c - 5 .. 16c + 15): 42 bits from bit 2 (src mod 4) of the eight bytes on
         const uint64_t w64 = ((((uint64_t)st.w.y << 32) | st.w.x) >> (2u * (st.src & 3u)));
         uint32_t cwa = (uint32_t)w64, cwb = (uint32_t)(w64 >> 16);
         const uint32_t slot = g * G + st.r + B.slot_offset;
         if (dg & 4u) { cwa = (g * G + st.r) * 2654435761u + c8; cwb = cwa * 40503u + 1u; }  // ablation: no haplotype fetch
         uint32_t sw[4], qw[4], fixv[2];
-        const bool st_ok = st.ok && !(dg & 1u);
-        const uint32_t so_ = st_ok ? st.out : 0xFFFFFFFFu;
-        const uint32_t qo_ = st_ok ? st.out + qual_at : 0xFFFFFFFFu;
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
           uint32_t x[8];
-          const uint32_t c = hf ? min(c8 + 1u, TIp_v - 1u) : c8, cw = hf ? cwb : cwa;   // (an idle second half redoes the last item)
+          const uint32_t c = c8 + (uint32_t)hf, cw = hf ? cwb : cwa;
           if (dg & 8u) {  // ablation: no Philox
 #pragma unroll
             for (int z = 0; z < 8; z++) x[z] = (slot * 2654435761u) ^ (c * 40503u + z * 0x9E3779B9u);
@@ -1822,26 +1823,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           const uint32_t so[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
           uint32_t s2[2], q2[2], acc;
           sample8(code4, lgW, cw, x, so, r2.x, r2.y, s2, q2, acc);
-          uint32_t fix_mask = (hf && !two) ? 0u : 0xFFu;
-          if (tail_whole) {  // (wave-uniform) the read's last item: its eighth byte is the line break, then "+\n"
-            const bool last = c + 1u == TI && (hf == 0 || two);
-            const uint32_t sel = last ? 0x04020100u : 0x03020100u;   // v_perm: byte 3 = the first operand's byte 0 / the second's own
-            s2[1] = __builtin_amdgcn_perm(0x0Au, s2[1], sel);
-            q2[1] = __builtin_amdgcn_perm(0x0Au, q2[1], sel);
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0x0A2Bu, out_rsrc, (last && st_ok) ? so_ + 8u * (uint32_t)hf + 8u : 0xFFFFFFFFu, 0, 0);
-            if (last) fix_mask = 0x7Fu;
-          }
           sw[2 * hf] = s2[0]; sw[2 * hf + 1] = s2[1];
           qw[2 * hf] = q2[0]; qw[2 * hf + 1] = q2[1];
-          fixv[hf] = (st.ok && !(dg & 16u)) ? (acc >> 17) & fix_mask : 0u;
+          fixv[hf] = (dg & 16u) ? 0u : (acc >> 17) & 0xFFu;
         }
-        // whole units leave as sixteen bytes per line, a read's odd last unit as eight (the other store is dropped)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{sw[0], sw[1], sw[2], sw[3]}, out_rsrc, two ? so_ : 0xFFFFFFFFu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, out_rsrc, two ? qo_ : 0xFFFFFFFFu, 0, 0);
-        if (TIp & 1u) {    // (wave-uniform: only then has a read an odd last unit)
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{sw[0], sw[1]}, out_rsrc, two ? 0xFFFFFFFFu : so_, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{qw[0], qw[1]}, out_rsrc, two ? 0xFFFFFFFFu : qo_, 0, 0);
-        }
+        const uint32_t so_ = (dg & 1u) ? 0xFFFFFFFFu : st.out;
+        const uint32_t qo_ = (dg & 1u) ? 0xFFFFFFFFu : st.out + qual_at;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{sw[0], sw[1], sw[2], sw[3]}, out_rsrc, so_, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{qw[0], qw[1], qw[2], qw[3]}, out_rsrc, qo_, 0, 0);
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
           const uint32_t fix = fixv[hf];
@@ -1854,39 +1843,37 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           }
         }
       };
-      P16 cur = fetch16(0);
-      // (dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
+      P16 cur = fetch16(a16);
+      // (two dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
-      if (TIp & 1u) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
-      }
-      if (tail_whole) {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0u, out_rsrc, 0xFFFFFFE0u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0u, out_rsrc, 0xFFFFFFE0u, 0, 0);
-      }
-      for (uint32_t step = 0; step < np16steps; step++) {
-        const P16 nxt = fetch16(min(step + 1u, np16steps - 1u));
+      for (uint32_t step = a16; step < b16; step++) {
+        const P16 nxt = fetch16(min(step + 1u, b16 - 1u));
         run16(cur);
         cur = nxt;
       }
     }
-    // ---- plain steps (8-base items): SG_FDIAG 512 only (the round-3 form of the plain steps, for comparisons) ----
-    if (npsteps) {
+    // ---- plain steps (8-base items): the reads' own odd last items, then the halves of the 16-base items the whole steps
+    // above left over ----
+    if (a8 < b8) {
       struct PStage { uint32_t r, c, src, out; bool ok; uint2 w; };
       // (wave-uniform values of every step held in vector registers: as scalars they were spilled and came back
       // through a v_readlane_b32 in every step)
-      uint32_t qual_at = (uint32_t)P.L + 3u, TIp_v = TIp;
-      asm volatile("" : "+v"(qual_at), "+v"(TIp_v));
-      const uint32_t inv_TIp = TIp ? (1u << 20) / TIp + 1u : 0u;
+      uint32_t qual_at = (uint32_t)P.L + 3u, n_single = n_plain * cnt8, i16_base = np16steps << 6;
+      asm volatile("" : "+v"(qual_at), "+v"(n_single), "+v"(i16_base));
+      const uint32_t inv_cnt8 = cnt8 ? (1u << 20) / cnt8 + 1u : 0u;
       auto fetch_plain = [&](uint32_t step) -> PStage {
         PStage st;
         const uint32_t i_raw = step * 64u + lane;
         st.ok = i_raw < n_pitems;
         const uint32_t i = min(i_raw, n_pitems - 1u);     // idle lanes redo the stream's last item, their stores are dropped
-        const uint32_t ri = __umul24(i, inv_TIp) >> 20;   // i / TIp
-        st.c = i - __umul24(ri, TIp_v);
+        const bool half = i >= n_single;                  // a read's own 8-base item / a half of a left-over 16-base item
+        const uint32_t j = i - n_single;
+        const uint32_t q = half ? i16_base + (j >> 1) : i;
+        const uint32_t d = half ? TI16 : cnt8;
+        const uint32_t ri = __umul24(q, half ? inv_TI16 : inv_cnt8) >> 20;  // q / d
+        const uint32_t rem = q - __umul24(ri, d);
+        st.c = half ? 2u * rem + (j & 1u) : c8_base + rem;
         st.r = permp[ri];
         const uint32_t* row = (const uint32_t*)(meta_rows + st.r * 2);
         const uint32_t A = row[1];
@@ -1939,17 +1926,18 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
           nfix += (uint32_t)__popcll(fm);
         }
       };
-      PStage cur = fetch_plain(0);
+      PStage cur = fetch_plain(a8);
       // (two dropped stores: every iteration then has the same vector-memory operations behind its prefetch, see below)
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFFFu, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, out_rsrc, 0xFFFFFFF0u, 0, 0);
       if (tail_whole) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0u, out_rsrc, 0xFFFFFFE0u, 0, 0);
-      for (uint32_t step = 0; step < npsteps; step++) {
-        const PStage nxt = fetch_plain(min(step + 1u, npsteps - 1u));
+      for (uint32_t step = a8; step < b8; step++) {
+        const PStage nxt = fetch_plain(min(step + 1u, b8 - 1u));
         run_plain(cur);
         cur = nxt;
       }
     }
+    }   // (the two phases)
     // ---- clean steps: the plain step with the read's own bins, length and (behind the indel) shifted template ----
     if (n_clean) {
       const uint32_t ncsteps = (dg & 128u) ? 0u : (n_clean + 63u) / 64u;
