@@ -13,13 +13,16 @@
 //   window scan           windows opened so far -> the read's window; read counts by atomics (one per thread and window)
 //   train_cigar_kernel    lane = counted line: the CIGAR walk of :290-382 (insertion / deletion length counts unless the VCF
 //                         knows the event; only a single nM goes on)
-//   train_count_kernel    wave = read, lane = base: subsDist1 / subsDist2 / kmersDist (:399-442), iSizeDist (:444-451),
-//                         qualityDist (:453-481) as 64-bit atomics
+//   train_count_lds_kernel  workgroup = a group of bins x a slice of the reads, sixteen lanes = read: subsDist1 / subsDist2 /
+//                         kmersDist (:399-442), qualityDist (:453-481) counted in LDS, added to memory once; iSizeDist
+//                         (:444-451).  (train_count_kernel: the same straight to memory, for tables that do not fit LDS)
 //   train_window_gc_kernel (at the end) wave = window: calculateGCContent (lib/mydefine/MyDefine.cpp:306-331)
 // Integer work throughout; results are exact counts.  The checker is oracle/train_oracle.cpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "sg_train.h"
 
@@ -438,86 +441,154 @@ __global__ __launch_bounds__(256) void train_cigar_kernel(TrainJob J) {
   J.reads[li].flags = R.flags | 16u;
 }
 
+// ---- the count matrices ----
+// What one base of a counted read adds (Profile.cpp:399-481), shared by the two kernels below; `Sink` says where the three
+// counters live.
+template <class Sink>
+__device__ __forceinline__ void count_base(const TrainJob& J, const TrainRead& R, uint32_t i, Sink& sink) {
+  const uint32_t K = J.kmer, bins = J.bins;
+  const bool has_alt = J.alt_codes != J.ref_codes;
+  const bool rev = (R.flags & 2u) != 0u;               // tlen < 0: everything reverse-complemented, mate 2 (:388-397)
+  const uint32_t n = R.len;
+  const char* seq = J.text + R.seq_off;
+  const char* qual = J.text + R.qual_off;
+  const uint8_t* ref = J.ref_codes + R.ref_off;
+  const uint8_t* alt = J.alt_codes + R.ref_off;
+  // index in `bases` of the base the k-mer context holds at read position q (:404-415: the alternative allele where the
+  // read shows it, else the reference base), and whether the read shows the alternative allele there
+  auto context_idx = [&](uint32_t q, bool* is_alt) -> int {
+    const uint32_t w = rev ? n - 1u - q : q;
+    uint32_t code = ref[w];
+    *is_alt = false;
+    if (has_alt) {
+      const uint32_t ac = alt[w];
+      if (ac != code) {
+        const char c = seq[w];
+        bool eq;
+        if (ac <= 3u) eq = c == "ACTG"[ac];
+        else eq = rev ? !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't')   // (both complement to 'N')
+                      : (ac == 4u && c == 'N');
+        if (eq) { code = ac; *is_alt = true; }
+      }
+    }
+    if (code > 3u) return -1;
+    if (rev) code ^= 2u;
+    return (int)((J.remap >> (2u * code)) & 3u);
+  };
+  const uint32_t j = rev ? n - 1u - i : i;           // index of read position i in the line's strings / the reference window
+  // read base -> index in `bases` (getIndexOfBase, MyDefine.cpp:228-236), complemented first on the reverse strand
+  // (Segment::getComplementSeq keeps the case, so lower-case bases stay unknown)
+  char c = seq[j];
+  if (rev) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
+  const int b = c == J.bases[0] ? 0 : c == J.bases[1] ? 1 : c == J.bases[2] ? 2 : c == J.bases[3] ? 3 : -1;
+  const uint32_t bin = (uint32_t)(((uint64_t)i * bins) / n);
+  bool shows_alt;
+  const int s0 = context_idx(i, &shows_alt);
+  if (b >= 0) {                                      // :416-442
+    const uint32_t m = i + 1u < K ? i + 1u : K;       // real bases of the context, the rest is 'X'
+    int kidx = (int)J.kmer_off[m];
+    int v = 0;
+    for (uint32_t t = 0; t < m; t++) {                // oldest base in the highest digit
+      bool dummy;
+      const int x = t + 1u == m ? s0 : context_idx(i + 1u - m + t, &dummy);
+      if (x < 0) { kidx = -1; break; }
+      v = v * 4 + x;
+    }
+    if (kidx >= 0) sink.sub(rev, (uint32_t)(kidx + v), bin, (uint32_t)b);
+  }
+  if ((R.flags & 4u) && b >= 0) {                    // :457-480
+    uint32_t rc = ref[j];                            // refSeq[i] itself must be a base (:460,463) ...
+    int r0 = -1;
+    if (rc <= 3u) { if (rev) rc ^= 2u; r0 = (int)((J.remap >> (2u * rc)) & 3u); }
+    if (r0 >= 0) {
+      if (shows_alt) r0 = s0;                        // ... and gives way to the alternative allele the read shows (:466-468)
+      const int q = (int)(signed char)qual[j];
+      if (r0 >= 0 && q >= 33 && q <= 126) sink.qual((uint32_t)(r0 * 4 + b), bin, (uint32_t)(q - 33));
+    }
+  }
+}
+
+__device__ __forceinline__ void count_read_scalars(const TrainJob& J, const TrainRead& R) {
+  if (R.tlen > 0) {                                  // :446-451
+    if ((uint32_t)R.tlen < J.n_isize) atomicAdd(J.isize + R.tlen, 1ull);
+    else atomicAdd(J.scalars + kTrainIsizeOverflow, 1ull);
+  }
+  atomicAdd(J.scalars + kTrainReads, 1ull);          // :483
+}
+
+// Straight to the tables in memory: wave = read, lane = base, 64-bit atomics.  For context lengths whose tables do not fit
+// LDS (kmer 6); three atomics per base on a few thousand hot cells -- 13 G atomics/s, 5.6 ms per 64 MB of text.
+struct GlobalSink {
+  const TrainJob& J;
+  __device__ void sub(bool rev, uint32_t kidx, uint32_t bin, uint32_t b) {
+    atomicAdd((rev ? J.subs2 : J.subs1) + ((size_t)kidx * J.bins + bin) * 4u + b, 1ull);
+    atomicAdd(J.kmers + (size_t)bin * J.kmer_count + kidx, 1ull);
+  }
+  __device__ void qual(uint32_t pair, uint32_t bin, uint32_t q) { atomicAdd(J.quality + ((size_t)pair * J.bins + bin) * 94u + q, 1ull); }
+};
 __global__ __launch_bounds__(256) void train_count_kernel(TrainJob J) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  const uint32_t K = J.kmer, bins = J.bins, kc = J.kmer_count;
-  const bool has_alt = J.alt_codes != J.ref_codes;
+  GlobalSink sink{J};
   for (uint64_t li = wave; li < J.n_lines; li += n_waves) {
     const TrainRead R = J.reads[li];
     if (!(R.flags & 16u)) continue;
-    const bool rev = (R.flags & 2u) != 0u;               // tlen < 0: everything reverse-complemented, mate 2 (:388-397)
-    const uint32_t n = R.len;
-    unsigned long long* subs = rev ? J.subs2 : J.subs1;
-    const char* seq = J.text + R.seq_off;
-    const char* qual = J.text + R.qual_off;
-    const uint8_t* ref = J.ref_codes + R.ref_off;
-    const uint8_t* alt = J.alt_codes + R.ref_off;
-    // index in `bases` of the base the k-mer context holds at read position q (:404-415: the alternative allele where the
-    // read shows it, else the reference base), and whether the read shows the alternative allele there
-    auto context_idx = [&](uint32_t q, bool* is_alt) -> int {
-      const uint32_t w = rev ? n - 1u - q : q;
-      uint32_t code = ref[w];
-      *is_alt = false;
-      if (has_alt) {
-        const uint32_t ac = alt[w];
-        if (ac != code) {
-          const char c = seq[w];
-          bool eq;
-          if (ac <= 3u) eq = c == "ACTG"[ac];
-          else eq = rev ? !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't')   // (both complement to 'N')
-                        : (ac == 4u && c == 'N');
-          if (eq) { code = ac; *is_alt = true; }
-        }
-      }
-      if (code > 3u) return -1;
-      if (rev) code ^= 2u;
-      return (int)((J.remap >> (2u * code)) & 3u);
-    };
-    for (uint32_t i = lane; i < n; i += 64u) {
-      const uint32_t j = rev ? n - 1u - i : i;           // index of read position i in the line's strings / the reference window
-      // read base -> index in `bases` (getIndexOfBase, MyDefine.cpp:228-236), complemented first on the reverse strand
-      // (Segment::getComplementSeq keeps the case, so lower-case bases stay unknown)
-      char c = seq[j];
-      if (rev) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
-      const int b = c == J.bases[0] ? 0 : c == J.bases[1] ? 1 : c == J.bases[2] ? 2 : c == J.bases[3] ? 3 : -1;
-      const uint32_t bin = (uint32_t)(((uint64_t)i * bins) / n);
-      bool shows_alt;
-      const int s0 = context_idx(i, &shows_alt);
-      if (b >= 0) {                                      // :416-442
-        const uint32_t m = i + 1u < K ? i + 1u : K;       // real bases of the context, the rest is 'X'
-        int kidx = (int)J.kmer_off[m];
-        int v = 0;
-        for (uint32_t t = 0; t < m; t++) {                // oldest base in the highest digit
-          bool dummy;
-          const int x = t + 1u == m ? s0 : context_idx(i + 1u - m + t, &dummy);
-          if (x < 0) { kidx = -1; break; }
-          v = v * 4 + x;
-        }
-        if (kidx >= 0) {
-          kidx += v;
-          atomicAdd(subs + ((size_t)kidx * bins + bin) * 4u + (uint32_t)b, 1ull);
-          atomicAdd(J.kmers + (size_t)bin * kc + (uint32_t)kidx, 1ull);
-        }
-      }
-      if ((R.flags & 4u) && b >= 0) {                    // :457-480
-        uint32_t rc = ref[j];                            // refSeq[i] itself must be a base (:460,463) ...
-        int r0 = -1;
-        if (rc <= 3u) { if (rev) rc ^= 2u; r0 = (int)((J.remap >> (2u * rc)) & 3u); }
-        if (r0 >= 0) {
-          if (shows_alt) r0 = s0;                        // ... and gives way to the alternative allele the read shows (:466-468)
-          const int q = (int)(signed char)qual[j];
-          if (r0 >= 0 && q >= 33 && q <= 126)
-            atomicAdd(J.quality + (((size_t)(r0 * 4 + b)) * bins + bin) * 94u + (uint32_t)(q - 33), 1ull);
-        }
-      }
-    }
-    if (lane == 0u) {
-      if (R.tlen > 0) {                                  // :446-451
-        if ((uint32_t)R.tlen < J.n_isize) atomicAdd(J.isize + R.tlen, 1ull);
-        else atomicAdd(J.scalars + kTrainIsizeOverflow, 1ull);
-      }
-      atomicAdd(J.scalars + kTrainReads, 1ull);          // :483
+    for (uint32_t i = lane; i < R.len; i += 64u) count_base(J, R, i, sink);
+    if (lane == 0u) count_read_scalars(J, R);
+  }
+}
+
+// The tables of a GROUP OF BINS in LDS: a workgroup counts the bases of `bpg` bins of its slice of the chunk's reads with
+// 32-bit LDS atomics and adds what it has to the tables in memory once, at its end.  bin = i * bins / n, so a group of bins
+// is a run of read positions: sixteen lanes take a read and walk that run (15 to 18 bases of a 151-base read with six of
+// fifty bins).  LDS: bpg x (2 mates x kc x 4 + kc + 16 x 94) counters.
+struct LdsSink {
+  uint32_t* subs;    // [2][kc][bpg][4]
+  uint32_t* kmers;   // [bpg][kc]
+  uint32_t* quals;   // [16][bpg][94]
+  uint32_t kc, bpg, b0;
+  __device__ void sub(bool rev, uint32_t kidx, uint32_t bin, uint32_t b) {
+    const uint32_t lb = bin - b0;
+    atomicAdd(subs + (((rev ? kc : 0u) + kidx) * bpg + lb) * 4u + b, 1u);
+    atomicAdd(kmers + lb * kc + kidx, 1u);
+  }
+  __device__ void qual(uint32_t pair, uint32_t bin, uint32_t q) { atomicAdd(quals + (pair * bpg + (bin - b0)) * 94u + q, 1u); }
+};
+__global__ __launch_bounds__(256) void train_count_lds_kernel(TrainJob J, uint32_t bpg, uint32_t n_groups, uint32_t reads_per_wg) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t kc = J.kmer_count, bins = J.bins;
+  const uint32_t n_sub = 2u * kc * bpg * 4u, n_km = bpg * kc, n_q = 16u * bpg * 94u, n_all = n_sub + n_km + n_q;
+  for (uint32_t i = threadIdx.x; i < n_all; i += blockDim.x) lds[i] = 0u;
+  __syncthreads();
+  const uint32_t g = blockIdx.x % n_groups;
+  const uint64_t r0 = (uint64_t)(blockIdx.x / n_groups) * reads_per_wg;
+  const uint64_t r1 = r0 + reads_per_wg < J.n_lines ? r0 + reads_per_wg : J.n_lines;
+  const uint32_t b0 = g * bpg, b1 = b0 + bpg < bins ? b0 + bpg : bins;
+  LdsSink sink{lds, lds + n_sub, lds + n_sub + n_km, kc, bpg, b0};
+  const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15u;   // sixteen groups of sixteen lanes
+  for (uint64_t li = r0 + sub; li < r1; li += 16u) {
+    const TrainRead R = J.reads[li];
+    if (!(R.flags & 16u)) continue;
+    const uint64_t n = R.len;
+    // positions whose bin lies in [b0, b1): i * bins / n >= b0  <=>  i >= ceil(b0 n / bins)
+    const uint32_t i_lo = (uint32_t)(((uint64_t)b0 * n + bins - 1u) / bins), i_hi = (uint32_t)(((uint64_t)b1 * n + bins - 1u) / bins);
+    for (uint32_t i = i_lo + l16; i < i_hi && i < R.len; i += 16u) count_base(J, R, i, sink);
+    if (g == 0u && l16 == 0u) count_read_scalars(J, R);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_all; i += blockDim.x) {
+    const uint32_t v = lds[i];
+    if (!v) continue;
+    if (i < n_sub) {
+      const uint32_t b = i & 3u, lb = (i >> 2) % bpg, k2 = (i >> 2) / bpg;   // k2 = mate * kc + kidx
+      const bool rev = k2 >= kc;
+      atomicAdd((rev ? J.subs2 : J.subs1) + ((size_t)(rev ? k2 - kc : k2) * bins + b0 + lb) * 4u + b, (unsigned long long)v);
+    } else if (i < n_sub + n_km) {
+      const uint32_t e = i - n_sub, lb = e / kc, kidx = e - lb * kc;
+      atomicAdd(J.kmers + (size_t)(b0 + lb) * kc + kidx, (unsigned long long)v);
+    } else {
+      const uint32_t e = i - n_sub - n_km, q = e % 94u, lb = (e / 94u) % bpg, pair = e / (94u * bpg);
+      atomicAdd(J.quality + ((size_t)pair * bins + b0 + lb) * 94u + q, (unsigned long long)v);
     }
   }
 }
@@ -586,6 +657,18 @@ void launch_train_chunk(const TrainJob& J, hipStream_t s) {
     run_scan(WindowOp{J}, J.n_lines, J.scan_work, s);
   }
   hipLaunchKernelGGL(train_cigar_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
+  // the count tables of as many bins as fit 60 KB of LDS; none do for kmer 6
+  const uint32_t per_bin = (9u * J.kmer_count + 16u * 94u) * 4u;
+  const uint32_t bpg = std::min<uint32_t>(J.bins, (60u << 10) / per_bin);
+  static const bool no_lds = getenv("SG_TRAIN_GLOBAL_ATOMICS") != nullptr;   // (tests: the two kernels count alike)
+  if (bpg >= 1u && !no_lds) {
+    const uint32_t n_groups = (J.bins + bpg - 1u) / bpg;
+    // ~8 workgroups per CU, at least 256 reads each
+    const uint64_t rpw = std::max<uint64_t>(256, (J.n_lines * n_groups + 2047) / 2048);
+    const uint32_t slices = (uint32_t)((J.n_lines + rpw - 1) / rpw);
+    hipLaunchKernelGGL(train_count_lds_kernel, dim3(slices * n_groups), dim3(256), bpg * per_bin, s, J, bpg, n_groups, (uint32_t)rpw);
+    return;
+  }
   const uint64_t waves = J.n_lines;
   const uint32_t grid = (uint32_t)(waves * 64 / 256 + 1 < 256u * 32u ? waves * 64 / 256 + 1 : 256u * 32u);
   hipLaunchKernelGGL(train_count_kernel, dim3(grid), dim3(256), 0, s, J);

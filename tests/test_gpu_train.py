@@ -269,6 +269,12 @@ def test_seqtoprofile_writes_the_profile_of_the_restatement(exome, oracle_lib, t
         assert open(want + ".gc", "rb").read() == open(got + ".gc", "rb").read()
     if not exome:
         assert os.path.exists(got + ".gc")   # 12x: the GC model is fitted
+    # the count tables straight in memory (the kernel of context lengths whose tables do not fit LDS): the same file
+    got3 = os.path.join(wd, "got3.profile")
+    r = subprocess.run([exe, "--sam", sam_path, "-v", vcf, "-r", fa, "-o", got3, "--quiet"] + (["-t", bed] if bed else []), capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, SG_TRAIN_GLOBAL_ATOMICS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(got3, "rb").read().split(b"\n", 1)[1] == b[1]
     # through standard input, as `samtools view ... | seqToProfile --sam -` would
     got2 = os.path.join(wd, "got2.profile")
     with open(sam_path, "rb") as f:
