@@ -256,6 +256,42 @@ def run_config(config_path: str, **opts) -> SimuStats:
     return st
 
 
+class SimuTrainOptions(C.Structure):
+    """simu_train_options (host/train.h): the options of the reference's seqToProfile + the additive ones"""
+    _fields_ = [("bam", C.c_char_p), ("sam", C.c_char_p), ("target", C.c_char_p), ("vcf", C.c_char_p), ("ref", C.c_char_p),
+                ("output", C.c_char_p), ("samtools", C.c_char_p), ("kmer", C.c_int32), ("bins", C.c_int32), ("device", C.c_int32),
+                ("threads", C.c_int32), ("quiet", C.c_int32), ("stamp", C.c_char_p)]
+
+
+class SimuTrainStats(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("reads_counted", C.c_uint64), ("gc_rejected", C.c_uint64), ("gc_windows", C.c_uint64),
+                ("gc_pairs", C.c_uint64), ("skipped_overhang", C.c_uint64), ("sam_bytes", C.c_uint64), ("read_length", C.c_int32),
+                ("bins", C.c_int32), ("gc_fitted", C.c_int32), ("t_reference", C.c_double), ("t_reads", C.c_double), ("t_total", C.c_double),
+                ("insert_rate", C.c_double), ("del_rate", C.c_double), ("std_isize", C.c_double), ("gc_std", C.c_double)]
+
+
+def train_profile(ref: str, vcf: str, output: str, sam: str = "", bam: str = "", target: str = "", samtools: str = "", kmer: int = 3,
+                  bins: int = 50, device: int = 0, quiet: int = 1, stamp: str = None) -> SimuTrainStats:
+    """`seqToProfile` in-process (src/seqToProfile.cpp main): reads (`sam`: a file of `samtools view` text, or `bam` through
+    samtools as the reference does), the sample's VCF and the reference -> a .profile file; the per-read work runs on the GPU."""
+    lib = load_host()
+    lib.simu_train_default_options.argtypes = [C.POINTER(SimuTrainOptions)]
+    lib.simu_train_default_options.restype = None
+    lib.simu_train.argtypes = [C.POINTER(SimuTrainOptions), C.POINTER(SimuTrainStats), C.c_char_p, C.c_size_t]
+    o = SimuTrainOptions()
+    lib.simu_train_default_options(C.byref(o))
+    o.bam, o.sam, o.target, o.vcf, o.ref, o.output, o.samtools = (x.encode() for x in (bam, sam, target, vcf, ref, output, samtools))
+    o.kmer, o.bins, o.device, o.quiet = kmer, bins, device, quiet
+    if stamp is not None:
+        o.stamp = stamp.encode()
+    st = SimuTrainStats()
+    err = C.create_string_buffer(4096)
+    rc = lib.simu_train(C.byref(o), C.byref(st), err, len(err))
+    if rc != 0:
+        raise SimuError(f"seqToProfile failed (exit code {rc}): {err.value.decode(errors='replace')}")
+    return st
+
+
 def release_cached_memory() -> None:
     """Device blocks that finished contexts left with the process go back to the runtime (sg_release_cached_memory)."""
     load_engine().sg_release_cached_memory()

@@ -1694,9 +1694,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // two of each; only WHOLE steps run that way.  What is left -- the 16-base items of the last, partial step, as their two
     // halves, and the reads' odd last 8-base item (cnt8 = TIp mod 2) -- goes through the 8-base plain steps as one stream,
     // so that neither loop ends in a step with idle lanes of its own.
-    const uint32_t n_p16 = (dg & 512u) ? 0u : n_plain * TI16;      // (SG_FDIAG 512: no 16-base steps)
+    // Reads of fewer than 18 whole items keep the 8-base steps alone: with four to seven pairs per read the whole 16-base steps
+    // cover 70 % of a group's items and the rest pays two loops' prologues -- the 125-, 75- and 74-base profiles ran 6-7 %
+    // SLOWER in pairs (2.75 / 3.36 / 3.41 ms against 2.59 / 3.14 / 3.18, profiles/r04_mid_all_profiles vs r03_final).
+    const bool use16 = !(dg & 512u) && TIp >= 18u;                 // (SG_FDIAG 512: no 16-base steps)
+    const uint32_t n_p16 = use16 ? n_plain * TI16 : 0u;
     const uint32_t np16steps = (dg & 128u) ? 0u : n_p16 >> 6, rem16 = n_p16 - (np16steps << 6);
-    const uint32_t cnt8 = (dg & 512u) ? TIp : TIp - 2u * TI16, c8_base = (dg & 512u) ? 0u : 2u * TI16;
+    const uint32_t cnt8 = use16 ? TIp - 2u * TI16 : TIp, c8_base = use16 ? 2u * TI16 : 0u;
     const uint32_t n_pitems = 2u * rem16 + n_plain * cnt8, npsteps = (dg & 128u) ? 0u : (n_pitems + 63u) / 64u;
     uint32_t cb = TI;
     // One item per lane.  A step's lane -> (read, item) map, its read rows and its haplotype window are fetched ONE STEP
@@ -1773,7 +1777,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_fast_kernel(DevProfile P, D
     // The odd items leave in the MIDDLE of their reads' pairs (round 4): a read's last bytes written nine steps behind its
     // pairs met the line gone from L2 (WRITE_SIZE 5.80 -> 6.99 M KiB per launch, profiles/r04_start); with the singles' step
     // between the two halves of the 16-base steps no instalment of a read is more than ~four steps from the other.
-    const uint32_t h16 = np16steps >> 1, s8_first = (cnt8 && npsteps) ? 1u : 0u;
+    const uint32_t h16 = np16steps >> 1, s8_first = (use16 && cnt8 && npsteps) ? 1u : 0u;   // (8-base steps alone: one loop, phase 1)
 #pragma unroll 1
     for (uint32_t ph = 0; ph < 2u; ph++) {
     const uint32_t a16 = ph ? h16 : 0u, b16 = ph ? np16steps : h16;

@@ -275,6 +275,11 @@ def test_seqtoprofile_writes_the_profile_of_the_restatement(exome, oracle_lib, t
                        timeout=600, env=dict(os.environ, SG_TRAIN_GLOBAL_ATOMICS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(got3, "rb").read().split(b"\n", 1)[1] == b[1]
+    # the library call (simu_train, host/train.h) with a fixed time-stamp line: the whole file
+    got4 = os.path.join(wd, "got4.profile")
+    st = simuscop_amd.train_profile(ref=fa, vcf=vcf, output=got4, sam=sam_path, target=bed or "", stamp="stamp\n")
+    assert open(got4, "rb").read() == open(want, "rb").read()
+    assert st.read_length == T.L and st.bins == 50 and st.reads_counted > 1000 and st.lines == sam.count(b"\n")
     # through standard input, as `samtools view ... | seqToProfile --sam -` would
     got2 = os.path.join(wd, "got2.profile")
     with open(sam_path, "rb") as f:
@@ -299,3 +304,112 @@ def test_seqtoprofile_writes_the_profile_of_the_restatement(exome, oracle_lib, t
             os.remove(os.path.join(out, f))
         assert oracle_lib.orc_simulate(cfg.encode(), 0, cases.FAKE_SEC, cases.FAKE_NSEC, b"", 1) == 0
         assert md5(out) == ref_md5 and ref_md5
+
+
+def _random_training_case(rng, wd):
+    """A small random input for countGC's scan: contigs of random sizes (some shorter than a window, X among them), reads at
+    random positions -- mostly ascending, with steps backwards, contig changes at random places, reads past contig ends --,
+    random targets (unsorted, overlapping, nested) or none, a few known variants."""
+    from simuscop_amd import synth
+    names = ["chr%d" % (i + 1) for i in range(rng.randrange(1, 6))] + (["chrX"] if rng.random() < 0.5 else [])
+    sizes = [rng.choice([300, 950, 1000, 1001, 2500, 7000, 20000]) for _ in names]
+    fa = os.path.join(wd, "ref.fa")
+    seqs = {}
+    with open(fa, "wb") as f:
+        for k, (n, L) in enumerate(zip(names, sizes)):
+            s = synth.synth_contig(L, rng.randrange(1, 10 ** 6), 0, n_runs=rng.random() < 0.3).tobytes()
+            seqs[n] = s
+            f.write(b">" + n.encode() + b"\n" + b"".join(s[i:i + 60] + b"\n" for i in range(0, len(s), 60)))
+    RL = rng.choice([36, 75, 100])
+    lines = []
+    cur = rng.choice(names)
+    pos = 1
+    for _ in range(rng.randrange(200, 3000)):
+        r = rng.random()
+        if r < 0.02:
+            cur, pos = rng.choice(names), 1
+        elif r < 0.06:
+            pos = max(1, pos - rng.randrange(1, 3000))
+        else:
+            pos += rng.choice([0, 0, 1, 3, 17, 60, 400, 1500])
+        size = len(seqs[cur])
+        if pos > size + 50:
+            cur, pos = rng.choice(names), 1
+            size = len(seqs[cur])
+        lines.append(TU._crafted(rng, cur.encode(), seqs[cur], pos, RL, rng.choice([-250, 0, 200, 300]),
+                                 cigar=rng.choice([None] * 8 + [b"10M2I%dM" % (RL - 12), b"10M3D%dM" % (RL - 10), b"5S%dM" % (RL - 5)]),
+                                 mapq=rng.choice([b"60"] * 9 + [b"3"])))
+    vcf = [b"##fileformat=VCFv4.2"]
+    for _ in range(rng.randrange(0, 12)):
+        n = rng.choice(names)
+        p = rng.randrange(1, len(seqs[n]))
+        kind = rng.random()
+        ref_b = seqs[n][p - 1:p].upper() or b"A"
+        if kind < 0.6:
+            row = [n.encode(), b"%d" % p, b".", ref_b, bytes([rng.choice(b"ACGT")]), b"50", b"PASS", b"DP=40", b"GT", rng.choice([b"0/1", b"1/1"])]
+        elif kind < 0.8:
+            row = [n.encode(), b"%d" % p, b".", ref_b, ref_b + b"AC", b"50", b"PASS", b"DP=40", b"GT", b"0/1"]
+        else:
+            row = [n.encode(), b"%d" % p, b".", ref_b + b"ACG", ref_b, b"50", b"PASS", b"DP=40", b"GT", b"0/1"]
+        vcf.append(b"\t".join(row))
+    vcf_path = os.path.join(wd, "k.vcf")
+    open(vcf_path, "wb").write(b"\n".join(vcf) + b"\n")
+    bed = None
+    if rng.random() < 0.5:
+        rows = []
+        for _ in range(rng.randrange(1, 25)):
+            n = rng.choice(names)
+            a = rng.randrange(0, len(seqs[n]))
+            rows.append(b"%s\t%d\t%d" % (n.encode(), a, a + rng.choice([1, 40, 300, 1200, 2600])))
+        bed = os.path.join(wd, "t.bed")
+        open(bed, "wb").write(b"\n".join(rows) + b"\n")
+    return fa, vcf_path, bed, b"\n".join(lines) + b"\n", RL
+
+
+def test_device_training_on_random_inputs(oracle_lib, tmp_path):
+    """Forty small random inputs (one process, one engine context): counters and (GC, read count) pairs against the
+    restatement, the text cut into chunks at random line ends."""
+    import random
+    import test_train_profile_cpu as TP
+    TP.declare(oracle_lib)
+    T = H.ProfileTables(oracle_lib, os.path.join(cases.TESTDATA, cases.PROFILES["xten"]), True, 350)
+    eng = simuscop_amd.load_engine()
+    for seed in range(40):
+        rng = random.Random(7000 + seed)
+        wd = str(tmp_path / ("c%d" % seed))
+        os.makedirs(wd)
+        fa, vcf, bed, sam, RL = _random_training_case(rng, wd)
+        bins = rng.choice([10, 50])
+        want, wa = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, bins, 2048)
+        cap = 20000
+        wgc, wrc, wn = (C.c_double * cap)(), (C.c_double * cap)(), C.c_uint64()
+        assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), (bed or "").encode(), T.bases.encode(), 3, bins, 2048, 256,
+                                    C.byref(want), wgc, wrc, cap, C.byref(wn)) == 0
+        ctx = C.c_void_p()
+        assert eng.sg_create(C.byref(ctx), 0, 1) == 0
+        try:
+            keys = _reference_on_device(eng, ctx, fa)
+            lens = [len(b"".join(part.split(b"\n")[1:])) for part in open(fa, "rb").read().split(b">")[1:]]
+            keep = []
+
+            class TT:   # (the setup helper reads .bases / .bins)
+                pass
+            tt = TT()
+            tt.bases, tt.bins = T.bases, bins
+            st = _setup_from_files(keys, lens, vcf, bed, tt, keep)
+            assert eng.sg_train_begin(ctx, C.byref(st)) == 0, eng.sg_last_error(ctx)
+            ends = [i + 1 for i, ch in enumerate(sam) if ch == 10]
+            cuts = sorted(set([0, len(sam)] + [rng.choice(ends) for _ in range(rng.randrange(0, 6))]))
+            for a, b in zip(cuts, cuts[1:]):
+                assert eng.sg_train_feed(ctx, sam[a:b], b - a) == 0, eng.sg_last_error(ctx)
+            got, ga = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, bins, 2048)
+            ggc, grc, gn = (C.c_double * cap)(), (C.c_double * cap)(), C.c_uint64()
+            assert eng.sg_train_finish(ctx, C.byref(got), ggc, grc, cap, C.byref(gn)) == 0, eng.sg_last_error(ctx)
+            try:
+                _same_counts(got, ga, want, wa)
+                assert gn.value == wn.value
+                assert list(ggc[:gn.value]) == list(wgc[:wn.value]) and list(grc[:gn.value]) == list(wrc[:wn.value])
+            except AssertionError as e:
+                raise AssertionError((seed, bool(bed), cuts, str(e)[:600]))
+        finally:
+            eng.sg_destroy(ctx)
