@@ -1431,6 +1431,8 @@ int sg_reference_commit(sg_ctx* ctx, const sg_contig* contigs, uint32_t n_contig
     const sg_contig& k = contigs[c];
     if (k.length && (k.line_bases == 0 || k.line_width < k.line_bases))
       return ctx->fail(SG_ERR_INVALID, "sg_reference_commit: contig " + std::to_string(c) + " has an impossible line shape");
+    if (k.length > 0xFFFFFFF0ull)   // (the ingest kernel's line / column arithmetic is 32-bit; the host says the same, fasta.cpp)
+      return ctx->fail(SG_ERR_UNSUPPORTED, "sg_reference_commit: contig " + std::to_string(c) + " is longer than 4 Gbp");
     const uint64_t lines = k.length ? (k.length - 1) / k.line_bases : 0;  // line breaks inside the contig
     if (k.raw_offset + k.length + lines * (k.line_width - k.line_bases) > ctx->ref_raw_bytes)
       return ctx->fail(SG_ERR_INVALID, "sg_reference_commit: contig " + std::to_string(c) + " runs past the end of the file");

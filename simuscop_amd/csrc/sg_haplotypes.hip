@@ -17,10 +17,16 @@ namespace sg {
 
 // base codes shared with sg_kernels.hip: A0 C1 T2 G3, 'N' = 4, 'X' = 6 (the k-mer trie's place holder, template_code in
 // sg_kernels.hip), anything else = 5
+// A0 C1 T2 G3, N 4, X 6 (the k-mer trie's place holder, Profile.cpp:94-101), anything else 5; letters in either case
+// (Segment.cpp:143 upper-cases the reference slice, :456 the variant alleles).  Without a branch: bytes 0x40..0x5F after
+// bit 5 is cleared index a 32 x 4-bit table held in two constants -- written with compares, the compiler made a chain of
+// wave-level branches per byte and the ingest kernel ran at 0.25 TB/s.
 __device__ __forceinline__ uint32_t encode_base(uint32_t b) {
-  if (b >= 'a' && b <= 'z') b -= 32u;  // Segment.cpp:143 (reference slice), :456 (variant alleles)
-  const bool acgt = (b == 'A') | (b == 'C') | (b == 'G') | (b == 'T');
-  return acgt ? ((b >> 1) & 3u) : (b == 'N' ? 4u : (b == 'X' ? 6u : 5u));
+  const uint32_t idx = (b & 0xDFu) - 0x40u;                 // 'A' 1, 'C' 3, 'G' 7, 'N' 14, 'T' 20, 'X' 24
+  const uint64_t t0 = 0x5455555535551505ull, t1 = 0x5555555655525555ull;   // entries 0-15, 16-31
+  const uint64_t t = (idx & 16u) ? t1 : t0;
+  const uint32_t v = (uint32_t)(t >> ((idx & 15u) * 4u)) & 0xFu;
+  return idx < 32u ? v : 5u;
 }
 
 // ---- header scan: offsets of '>' / '@' at a line start; ';' comment lines raise flag 1 ----------
@@ -69,17 +75,53 @@ __global__ __launch_bounds__(256) void ref_ingest_kernel(const uint8_t* __restri
     }
     const DevContig c = contigs[lo];
     const uint64_t i0 = (blk - c.first_block) * 16;
-    uint64_t line = i0 / c.line_bases;
-    uint32_t r = (uint32_t)(i0 - line * c.line_bases);
-    uint64_t src = c.raw_off + line * c.line_width + r;
+    // (a contig holds fewer than 2^32 bases -- the host refuses longer ones --, so line and column are 32-bit divisions:
+    // the 64-bit one was most of this kernel's 12.7 ms on a 3.1 Gbp genome)
+    const uint32_t line = (uint32_t)i0 / c.line_bases;
+    uint32_t r = (uint32_t)i0 - line * c.line_bases;
+    uint64_t src = c.raw_off + (uint64_t)line * c.line_width + r;
     const uint32_t nl = c.line_width - c.line_bases;
-    uint32_t out[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
     bool bad = false;
     const uint32_t nb = (uint32_t)(c.length - i0 < 16 ? c.length - i0 : 16);
+    if (nb == 16u && c.line_bases >= 16u) {
+      // Sixteen bases that meet at most one line end (every lane but a contig's last): two unaligned 16-byte loads -- the
+      // bytes up to the line end from the first, the bytes behind it from the second, taken nl bytes on -- instead of a
+      // byte loop that the whole wave walked for the one lane in four that crosses a line end.
+      const uint32_t first_len = c.line_bases - r;            // bases left in this line (>= 1)
+      uint4 va, vb;
+      __builtin_memcpy(&va, raw + src, 16);
+      vb = va;
+      if (first_len < 16u) __builtin_memcpy(&vb, raw + src + nl, 16);
+      if (first_len <= 16u && i0 + first_len < c.length)      // the line end inside or right behind the block: its bytes
+        for (uint32_t t = 0; t < nl; t++) { const uint32_t e = raw[src + first_len + t]; bad |= !((e == '\n') | (e == '\r')); }
+      auto pick = [&](uint32_t a, uint32_t b2, uint32_t q) {   // word q: bytes below first_len from a, the rest from b2
+        const uint32_t lo4 = 4u * q;
+        const uint32_t m = first_len >= lo4 + 4u ? 0xFFFFFFFFu : (first_len <= lo4 ? 0u : (1u << (8u * (first_len - lo4))) - 1u);
+        return (a & m) | (b2 & ~m);
+      };
+      auto enc4 = [&](uint32_t w) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int z = 0; z < 4; z++) {
+          const uint32_t b = (w >> (8 * z)) & 0xFFu;
+          bad |= (b == '\n') | ((b == '\r') & (nl != 0u));
+          o |= encode_base(b) << (8 * z);
+        }
+        return o;
+      };
+      const uint4 o = make_uint4(enc4(pick(va.x, vb.x, 0)), enc4(pick(va.y, vb.y, 1)), enc4(pick(va.z, vb.z, 2)), enc4(pick(va.w, vb.w, 3)));
+      if (bad) atomicOr(flags, 2u);
+      *(uint4*)(codes + c.code_off + i0) = o;
+      continue;
+    }
+    // (a contig's last block, or lines shorter than a block: byte by byte)
+    uint64_t wlo = 0x0404040404040404ull, whi = 0x0404040404040404ull;
     for (uint32_t k = 0; k < nb; k++) {
       const uint32_t b = raw[src];
       bad |= (b == '\n') | ((b == '\r') & (nl != 0u));
-      out[k >> 2] = (out[k >> 2] & ~(0xFFu << ((k & 3) * 8))) | (encode_base(b) << ((k & 3) * 8));
+      const uint64_t v8 = (uint64_t)encode_base(b), sh = (uint64_t)(k & 7u) * 8u;
+      if (k < 8u) wlo = (wlo & ~(0xFFull << sh)) | (v8 << sh);
+      else whi = (whi & ~(0xFFull << sh)) | (v8 << sh);
       src++;
       if (++r == c.line_bases) {
         if (i0 + k + 1 < c.length)  // not after the contig's last base (the file may end without a newline)
@@ -89,7 +131,7 @@ __global__ __launch_bounds__(256) void ref_ingest_kernel(const uint8_t* __restri
       }
     }
     if (bad) atomicOr(flags, 2u);
-    *(uint4*)(codes + c.code_off + i0) = make_uint4(out[0], out[1], out[2], out[3]);  // code_off is 16-aligned
+    *(uint4*)(codes + c.code_off + i0) = make_uint4((uint32_t)wlo, (uint32_t)(wlo >> 32), (uint32_t)whi, (uint32_t)(whi >> 32));  // code_off is 16-aligned
   }
 }
 

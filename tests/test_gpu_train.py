@@ -413,3 +413,41 @@ def test_device_training_on_random_inputs(oracle_lib, tmp_path):
                 raise AssertionError((seed, bool(bed), cuts, str(e)[:600]))
         finally:
             eng.sg_destroy(ctx)
+
+
+def test_seqtoprofile_refusals(tmp_path):
+    """What the reference's trainer refuses, with its exit codes: unreadable VCF / target / read files (exit(-1)), a line with
+    fewer than eleven fields (exit(1), Profile.cpp:246-251); and no read with a single match, where the reference's
+    setReadLength would run off its buffer."""
+    from simuscop_amd import synth
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "r.fa")
+    seq = synth.synth_contig(5000, 3, 0, n_runs=False).tobytes()
+    open(fa, "wb").write(b">chr1\n" + b"".join(seq[i:i + 60] + b"\n" for i in range(0, len(seq), 60)))
+    vcf = os.path.join(wd, "k.vcf")
+    open(vcf, "w").write("##fileformat=VCFv4.2\n")
+    import random
+    rng = random.Random(1)
+    good = [TU._crafted(rng, b"chr1", seq, p, 50, 200) for p in range(1, 4000, 7)]
+    sam = os.path.join(wd, "ok.sam")
+    open(sam, "wb").write(b"\n".join(good) + b"\n")
+    exe = os.path.join(ROOT, "simuscop_amd", "lib", "seqToProfile")
+
+    def run(*a):
+        return subprocess.run([exe, *a, "--quiet"], capture_output=True, text=True, timeout=300)
+    r = run("--sam", sam, "-v", vcf, "-r", fa, "-o", os.path.join(wd, "p.profile"))
+    assert r.returncode == 0, r.stderr[-1000:]
+    r = run("--sam", sam, "-v", os.path.join(wd, "none.vcf"), "-r", fa, "-o", os.path.join(wd, "p2"))
+    assert r.returncode == 255 and "cannot open VCF file" in r.stderr
+    r = run("--sam", os.path.join(wd, "none.sam"), "-v", vcf, "-r", fa, "-o", os.path.join(wd, "p2"))
+    assert r.returncode == 255 and "cannot open SAM file" in r.stderr
+    r = run("--sam", sam, "-v", vcf, "-r", fa, "-t", os.path.join(wd, "none.bed"), "-o", os.path.join(wd, "p2"))
+    assert r.returncode == 255 and "can not open target file" in r.stderr
+    bad = os.path.join(wd, "bad.sam")
+    open(bad, "wb").write(b"\n".join(good[:100] + [b"r\t0\tchr1\t10\t60"] + good[100:]) + b"\n")
+    r = run("--sam", bad, "-v", vcf, "-r", fa, "-o", os.path.join(wd, "p2"))
+    assert r.returncode == 1 and "malformed read" in r.stderr and "11 mandatory fields" in r.stderr
+    clipped = os.path.join(wd, "clipped.sam")
+    open(clipped, "wb").write(b"\n".join(l.replace(b"\t50M\t", b"\t5S45M\t") for l in good) + b"\n")
+    r = run("--sam", clipped, "-v", vcf, "-r", fa, "-o", os.path.join(wd, "p2"))
+    assert r.returncode == 1 and "single match" in r.stderr
