@@ -35,6 +35,13 @@ __global__ __launch_bounds__(256) void ref_scan_kernel(const uint8_t* __restrict
   for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
     uint4 w = *(const uint4*)(raw + i);  // the raw buffer is padded to a multiple of 16
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    // sixteen bytes without any of the three characters (all but a handful of a genome's blocks): one test, no byte loop
+    // (a branch per byte made this scan 0.94 G scalar instructions for 3.1 GB)
+    auto has = [](uint32_t x, uint32_t pat) { const uint32_t y = x ^ pat; return (y - 0x01010101u) & ~y & 0x80808080u; };
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) any |= has(ws[q], 0x3E3E3E3Eu) | has(ws[q], 0x40404040u) | has(ws[q], 0x3B3B3B3Bu);
+    if (!any) continue;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const uint32_t b = (ws[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
