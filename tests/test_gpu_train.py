@@ -291,6 +291,24 @@ def test_seqtoprofile_writes_the_profile_of_the_restatement(exome, oracle_lib, t
                      (["--sam", sam_path, "-v", vcf, "-r", fa, "-k", "6"], "maximum value of 5"), (["--sam", sam_path, "-v", vcf, "-r", fa, "-B", "9"], "minimum value of 10")):
         r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=120)
         assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr[-300:])
+    if not exome:
+        # the trained profile drives the GPU sampler like a shipped one: simuReads on it = oracle(philox) on it, byte for byte
+        cfg2, out2, out3 = os.path.join(wd, "sim2.txt"), os.path.join(wd, "sim2_gpu"), os.path.join(wd, "sim2_orc")
+        cases._config(cfg2, ref=fa1, profile=got, name="t", output=os.path.join(wd, "unused"), layout="PE", threads=1, verbose=0, coverage=2,
+                      insertSize=350, ploidy=2)
+        r = subprocess.run([SIMU, cfg2, "--seed", "4242", "--out", out2, "--quiet"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert oracle_lib.orc_simulate(cfg2.encode(), 1, 4242 >> 32, 4242 & 0xFFFFFFFF, out3.encode(), 4) == 0, oracle_lib.orc_last_error().decode()
+        files = sorted(os.listdir(out3))
+        assert files == sorted(os.listdir(out2)) and len(files) == 2
+        for f in files:
+            assert open(os.path.join(out2, f), "rb").read() == open(os.path.join(out3, f), "rb").read(), f
+        # five-base contexts, twenty bins (the count tables of ONE bin per workgroup fill the LDS budget)
+        want5, got5 = os.path.join(wd, "want5.profile"), os.path.join(wd, "got5.profile")
+        assert oracle_lib.orc_train_profile(sam, len(sam), fa.encode(), vcf.encode(), b"", b"ACTG", 5, 20, want5.encode(), sam_path.encode(), b"stamp\n") == 0
+        r = subprocess.run([exe, "--sam", sam_path, "-v", vcf, "-r", fa, "-o", got5, "-k", "5", "-B", "20", "--quiet"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(want5, "rb").read().split(b"\n", 1)[1] == open(got5, "rb").read().split(b"\n", 1)[1]
     REF, SHIM = os.path.join(ROOT, "oracle", "_ref", "simuReads"), os.path.join(ROOT, "oracle", "_ref", "libfakeclock.so")
     if os.path.exists(REF) and not exome:
         cfg, out = os.path.join(wd, "sim.txt"), os.path.join(wd, "sim_out")
