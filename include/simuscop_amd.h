@@ -326,7 +326,8 @@ int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
  * the contigs committed with sg_reference_commit (upper-cased, Genome.cpp:529); `contig_keys` names them in that order as the
  * FASTA index does (first token, chr / chrom prefix stripped, Fasta.cpp:58-69).
  *   sg_train_begin   tables zeroed, targets and known variants staged (refSequence / altSequence of Genome.cpp:466-475)
- *   sg_train_feed    one chunk of WHOLE lines, in file order; state is carried from chunk to chunk
+ *   sg_train_feed    one chunk of WHOLE lines, in file order; state is carried from chunk to chunk (once the cap of
+ *                    Profile::processRead has been reached, further chunks are ignored, as the reference stops reading)
  *   sg_train_finish  the count matrices; the (GC content, read count) pairs countGC pushed, in its order (gcs, readCounts)
  * Where the reference's behaviour is undefined the line is skipped and counted: reads hanging over their contig's end
  * (skipped_overhang).  Arrays are the caller's: subs1 / subs2 [kmer_count][bins][4], kmers [bins][kmer_count], quality
@@ -340,6 +341,9 @@ typedef struct sg_train_setup {
   uint32_t n_indel_len;    /* columns of insFreqs / delFreqs kept (longer events: indel_len_overflow) */
   int32_t count_gc;        /* 1: Profile::countGC gates and counts as the reference does; 0: every read through the filters counts */
   uint32_t window;         /* Segment::fragSize (1000) */
+  uint64_t max_reads;      /* Profile::processRead's maxCount (Profile.cpp:236, 497-507): the run ends with the read that makes the
+                            * count of counted reads reach it (twice it with targets); lines behind that one are never read.
+                            * 0 = the reference's 300,000,000 */
   /* exome: inTargets[chr] after loadTargets + divideTargets (Genome.cpp:238-299, 684-739), in that order; the rows of contig c
    * are [target_first[c], target_first[c + 1]); spos / epos as the reference holds them.  NULL / no rows: whole genome. */
   const uint64_t* target_first;
@@ -353,10 +357,12 @@ typedef struct sg_train_setup {
 typedef struct sg_train_counts {
   uint64_t *subs1, *subs2, *kmers, *quality, *isize, *ins_len, *del_len;
   uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, indel_len_overflow, skipped_overhang,
-      gc_rejected, gc_windows;
+      gc_rejected, gc_windows, capped;   /* capped: 1 when the run ended at max_reads */
 } sg_train_counts;
 int sg_train_begin(sg_ctx* ctx, const sg_train_setup* setup);
 int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes);
+/* 1 once the cap on counted reads has been reached (the caller may stop reading its input), else 0 */
+int sg_train_capped(sg_ctx* ctx);
 /* gc / rc: room for `gc_cap` pairs (NULL: none wanted); *n_gc = how many there are (SG_ERR_OVERFLOW when gc_cap is too small;
  * call again).  The session ends with a successful call or with sg_train_end. */
 int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, uint64_t gc_cap, uint64_t* n_gc);

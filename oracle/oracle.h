@@ -68,13 +68,14 @@ int orc_predict_philox(const orc_profile*, const char* ref, int n, int is_read1,
 typedef struct orc_train_counts {
   uint64_t *subs1, *subs2, *kmers, *quality, *isize, *ins_len, *del_len;
   uint64_t lines, reads_counted, cigar_chars, insert_events, delete_events, isize_overflow, indel_len_overflow, skipped_overhang,
-      gc_rejected, gc_windows;
+      gc_rejected, gc_windows, capped;
 } orc_train_counts;
 int orc_train_count(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* bases, int kmer, int bins,
                     uint32_t n_isize, uint32_t n_indel_len, orc_train_counts* out);
 int orc_train(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* vcf_path, const char* bed_path,
               const char* bases, int kmer, int bins, uint32_t n_isize, uint32_t n_indel_len, orc_train_counts* out,
               double* gc, double* rc, uint64_t cap, uint64_t* n_gc);
+void orc_train_set_max_reads(uint64_t n);   /* Profile.cpp:236 `maxCount` for the following calls; 0 = 300,000,000 */
 int orc_train_profile(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* vcf_path, const char* bed_path,
                       const char* bases, int kmer, int bins, const char* out_path, const char* bam_label, const char* stamp);
 

@@ -146,6 +146,8 @@ struct TrainState : Trainer {
   double insertRate = 0, delRate = 0, baseCount = 0;
   std::vector<double> gcs, readCounts;
   uint64_t lines = 0, reads_counted = 0, skipped_overhang = 0, gc_rejected = 0, gc_windows = 0;
+  uint64_t maxCount = 300000000;   // Profile::processRead's `maxCount` (:236): training stops at so many counted reads (twice
+  bool stopped = false;            // as many with targets, :497-507)
   // countGC's statics (Profile.cpp:514-525)
   string preChr = "";
   long refLen = 0, rightPos = 0, leftPos = -1;
@@ -200,8 +202,8 @@ struct TrainState : Trainer {
       string chr = abbrOfChr(el[0]);
       long pos = atol(el[1].c_str());
       string gt = el[9].substr(0, el[9].find(':'));
-      while (!gt.empty() && (gt.back() == '\n' || gt.back() == '\r')) gt.pop_back();
-      // (`1/1` is filed as heterozygous and everything else as homozygous, vcfparser.cpp:81-86: kept)
+      // (`1/1` is filed as heterozygous and everything else as homozygous, vcfparser.cpp:81-86: kept -- and so is what
+      // fgets leaves: a sample column that is the genotype alone ends in the line break, "1/1\n" is not "1/1")
       const bool homo = gt != "1/1";
       if (el[3].size() > 1) dels[chr].push_back(KnownIndel{pos + 1, (int)el[3].size() - 1});
       else if (el[4].size() > 1) inserts[chr].push_back(KnownIndel{pos, (int)el[4].size() - 1});
@@ -486,6 +488,7 @@ struct TrainState : Trainer {
       }
     }
     reads_counted++;                                    // :483
+    if (reads_counted >= (inTargets.empty() ? maxCount : 2 * maxCount)) return 2;   // :497-507: the caller stops reading
     return 0;
   }
 
@@ -495,7 +498,10 @@ struct TrainState : Trainer {
     while (p < end) {
       const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
       const char* le = nl ? nl : end;
-      if (processRead(string(p, le))) return 1;
+      if (stopped) return 0;                            // (Profile::train left its loop, :1461-1464)
+      const int ret = processRead(string(p, le));
+      if (ret == 1) return 1;
+      if (ret == 2) stopped = true;
       p = nl ? nl + 1 : end;
     }
     return 0;
@@ -512,7 +518,7 @@ struct TrainState : Trainer {
     for (size_t i = n_indel_len; i < delFreqs.size(); i++) out->indel_len_overflow += (uint64_t)delFreqs[i];
     out->lines = lines; out->reads_counted = reads_counted; out->cigar_chars = (uint64_t)baseCount;
     out->insert_events = (uint64_t)insertRate; out->delete_events = (uint64_t)delRate;
-    out->skipped_overhang = skipped_overhang; out->gc_rejected = gc_rejected; out->gc_windows = gc_windows;
+    out->skipped_overhang = skipped_overhang; out->gc_rejected = gc_rejected; out->gc_windows = gc_windows; out->capped = stopped ? 1 : 0;
   }
 
   // ---- the second half of Profile::train ----
@@ -743,11 +749,14 @@ int readLengthOf(const char* sam_text, uint64_t sam_bytes) {
   return 0;
 }
 
+uint64_t g_max_reads = 0;   // orc_train_set_max_reads: 0 = the reference's 300,000,000
+
 int setupState(TrainState& T, const char* fasta_path, const char* vcf_path, const char* bed_path, const char* bases, int kmer, int bins, int count_gc) {
   T.bases = bases;
   T.kmer = kmer;
   T.bins = bins;
   T.count_gc = count_gc != 0;
+  if (g_max_reads) T.maxCount = g_max_reads;
   T.init();
   T.loadFastaOrdered(fasta_path);
   if (vcf_path && *vcf_path && T.parseVcf(vcf_path)) return 2;
@@ -756,6 +765,9 @@ int setupState(TrainState& T, const char* fasta_path, const char* vcf_path, cons
 }
 
 }  // namespace
+
+// Profile::processRead's `maxCount` for the calls that follow (tests: a small cap shows the cut; 0 = the reference's)
+extern "C" void orc_train_set_max_reads(uint64_t n) { g_max_reads = n; }
 
 extern "C" int orc_train_count(const char* sam_text, uint64_t sam_bytes, const char* fasta_path, const char* bases, int kmer, int bins,
                                uint32_t n_isize, uint32_t n_indel_len, orc_train_counts* out) {

@@ -28,7 +28,7 @@ ENGINE_SYMBOLS = [
     "sg_gc_percent", "sg_set_profiling", "sg_kernel_times", "sg_emit_info", "sg_emit_variant", "sg_cdf_count_le", "sg_fetch_range", "sg_host_alloc",
     "sg_sub_row_identity_first", "sg_row_symbols", "sg_alias_row", "sg_window_weights", "sg_windows_build", "sg_plan_windows", "sg_plan_range", "sg_windows_drop",
     "sg_host_free", "sg_profile_prepare", "sg_profile_tables_error", "sg_load_prepared_profile", "sg_profile_tables_free", "sg_train_count",
-    "sg_train_begin", "sg_train_feed", "sg_train_finish", "sg_train_end",
+    "sg_train_begin", "sg_train_feed", "sg_train_capped", "sg_train_finish", "sg_train_end",
     "sg_release_cached_memory",
 ]
 
@@ -40,13 +40,14 @@ class SgTrainCounts(C.Structure):
                 ("ins_len", C.POINTER(C.c_uint64)), ("del_len", C.POINTER(C.c_uint64)),
                 ("lines", C.c_uint64), ("reads_counted", C.c_uint64), ("cigar_chars", C.c_uint64), ("insert_events", C.c_uint64),
                 ("delete_events", C.c_uint64), ("isize_overflow", C.c_uint64), ("indel_len_overflow", C.c_uint64),
-                ("skipped_overhang", C.c_uint64), ("gc_rejected", C.c_uint64), ("gc_windows", C.c_uint64)]
+                ("skipped_overhang", C.c_uint64), ("gc_rejected", C.c_uint64), ("gc_windows", C.c_uint64), ("capped", C.c_uint64)]
 
 
 class SgTrainSetup(C.Structure):
     """sg_train_setup (include/simuscop_amd.h)"""
     _fields_ = [("contig_keys", C.POINTER(C.c_char_p)), ("n_contigs", C.c_uint32), ("bases", C.c_char_p), ("kmer", C.c_int32),
                 ("bins", C.c_int32), ("n_isize", C.c_uint32), ("n_indel_len", C.c_uint32), ("count_gc", C.c_int32), ("window", C.c_uint32),
+                ("max_reads", C.c_uint64),
                 ("target_first", C.POINTER(C.c_uint64)), ("target_spos", C.POINTER(C.c_int64)), ("target_epos", C.POINTER(C.c_int64)),
                 ("n_snv", C.c_uint64), ("snv_contig", C.POINTER(C.c_uint32)), ("snv_pos", C.POINTER(C.c_int64)), ("snv_alt", C.c_char_p),
                 ("snv_homo", C.POINTER(C.c_uint8)),
@@ -150,6 +151,7 @@ def load_engine():
                                    C.c_uint32, C.c_uint32, C.POINTER(SgTrainCounts)]
     lib.sg_train_begin.argtypes = [vp, C.POINTER(SgTrainSetup)]
     lib.sg_train_feed.argtypes = [vp, C.c_char_p, C.c_uint64]
+    lib.sg_train_capped.argtypes = [vp]
     lib.sg_train_finish.argtypes = [vp, C.POINTER(SgTrainCounts), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)]
     lib.sg_train_end.argtypes = [vp]
     lib.sg_train_end.restype = None
@@ -260,18 +262,18 @@ class SimuTrainOptions(C.Structure):
     """simu_train_options (host/train.h): the options of the reference's seqToProfile + the additive ones"""
     _fields_ = [("bam", C.c_char_p), ("sam", C.c_char_p), ("target", C.c_char_p), ("vcf", C.c_char_p), ("ref", C.c_char_p),
                 ("output", C.c_char_p), ("samtools", C.c_char_p), ("kmer", C.c_int32), ("bins", C.c_int32), ("device", C.c_int32),
-                ("threads", C.c_int32), ("quiet", C.c_int32), ("stamp", C.c_char_p)]
+                ("threads", C.c_int32), ("quiet", C.c_int32), ("stamp", C.c_char_p), ("max_reads", C.c_uint64)]
 
 
 class SimuTrainStats(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("reads_counted", C.c_uint64), ("gc_rejected", C.c_uint64), ("gc_windows", C.c_uint64),
                 ("gc_pairs", C.c_uint64), ("skipped_overhang", C.c_uint64), ("sam_bytes", C.c_uint64), ("read_length", C.c_int32),
-                ("bins", C.c_int32), ("gc_fitted", C.c_int32), ("t_reference", C.c_double), ("t_reads", C.c_double), ("t_total", C.c_double),
+                ("bins", C.c_int32), ("gc_fitted", C.c_int32), ("capped", C.c_int32), ("t_reference", C.c_double), ("t_reads", C.c_double), ("t_total", C.c_double),
                 ("insert_rate", C.c_double), ("del_rate", C.c_double), ("std_isize", C.c_double), ("gc_std", C.c_double)]
 
 
 def train_profile(ref: str, vcf: str, output: str, sam: str = "", bam: str = "", target: str = "", samtools: str = "", kmer: int = 3,
-                  bins: int = 50, device: int = 0, quiet: int = 1, stamp: str = None) -> SimuTrainStats:
+                  bins: int = 50, device: int = 0, quiet: int = 1, stamp: str = None, max_reads: int = 0) -> SimuTrainStats:
     """`seqToProfile` in-process (src/seqToProfile.cpp main): reads (`sam`: a file of `samtools view` text, or `bam` through
     samtools as the reference does), the sample's VCF and the reference -> a .profile file; the per-read work runs on the GPU."""
     lib = load_host()
@@ -281,7 +283,7 @@ def train_profile(ref: str, vcf: str, output: str, sam: str = "", bam: str = "",
     o = SimuTrainOptions()
     lib.simu_train_default_options(C.byref(o))
     o.bam, o.sam, o.target, o.vcf, o.ref, o.output, o.samtools = (x.encode() for x in (bam, sam, target, vcf, ref, output, samtools))
-    o.kmer, o.bins, o.device, o.quiet = kmer, bins, device, quiet
+    o.kmer, o.bins, o.device, o.quiet, o.max_reads = kmer, bins, device, quiet, max_reads
     if stamp is not None:
         o.stamp = stamp.encode()
     st = SimuTrainStats()

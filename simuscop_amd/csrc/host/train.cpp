@@ -92,8 +92,9 @@ void parse_vcf(const std::string& path, const std::map<std::string, uint32_t>& r
     const long pos = atol(f[1]);
     std::string gt = f[9];
     gt = gt.substr(0, gt.find(':'));
-    while (!gt.empty() && (gt.back() == '\n' || gt.back() == '\r')) gt.pop_back();
-    const bool homo = gt != "1/1";   // (the parser files 1/1 as het and everything else as homo, :81-86: kept as it is)
+    // (the parser files 1/1 as het and everything else as homo, :81-86: kept as it is -- including what fgets leaves behind:
+    // a sample column that holds the genotype alone ends in the line break, and "1/1\n" is not "1/1")
+    const bool homo = gt != "1/1";
     const auto it = row_of.find(chr);
     const size_t ref_len = strlen(f[3]), alt_len = strlen(f[4]);
     if (ref_len > 1) {
@@ -494,7 +495,7 @@ void run(const simu_train_options& o, simu_train_stats& st) {
   memset(&S, 0, sizeof S);
   S.contig_keys = keys.data(); S.n_contigs = (uint32_t)keys.size();
   S.bases = M.bases.c_str(); S.kmer = M.kmer; S.bins = M.bins;
-  S.n_isize = kIsizeCols; S.n_indel_len = kIndelCols; S.count_gc = 1; S.window = kWindow;
+  S.n_isize = kIsizeCols; S.n_indel_len = kIndelCols; S.count_gc = 1; S.window = kWindow; S.max_reads = o.max_reads;
   if (!tspos.empty()) { S.target_first = tfirst.data(); S.target_spos = tspos.data(); S.target_epos = tepos.data(); }
   S.n_snv = kv.snv_pos.size(); S.snv_contig = kv.snv_contig.data(); S.snv_pos = kv.snv_pos.data(); S.snv_alt = kv.snv_alt.data(); S.snv_homo = kv.snv_homo.data();
   S.n_ins = kv.ins_pos.size(); S.ins_contig = kv.ins_contig.data(); S.ins_pos = kv.ins_pos.data(); S.ins_len = kv.ins_len.data();
@@ -515,7 +516,7 @@ void run(const simu_train_options& o, simu_train_stats& st) {
     if (!reader_error.empty()) throw Error(reader_error);
     st.sam_bytes += rd->len[cur];
     cur ^= 1;
-    have = more;
+    have = more && !sg_train_capped(eng.ctx);   // (at the cap the reference leaves its loop: the rest of the input is not read)
   }
   const size_t subs_n = (size_t)M.kmer_count * M.bins * 4, kmers_n = (size_t)M.bins * M.kmer_count, qual_n = (size_t)16 * M.bins * 94;
   std::vector<uint64_t> c_subs1(subs_n), c_subs2(subs_n), c_kmers(kmers_n), c_qual(qual_n), c_isize(kIsizeCols), c_ins(kIndelCols), c_del(kIndelCols);
@@ -575,6 +576,7 @@ void run(const simu_train_options& o, simu_train_stats& st) {
   }
   st.lines = C.lines; st.reads_counted = C.reads_counted; st.gc_rejected = C.gc_rejected; st.gc_windows = C.gc_windows;
   st.gc_pairs = n_gc; st.skipped_overhang = C.skipped_overhang; st.read_length = read_length; st.bins = M.bins;
+  st.capped = (int32_t)C.capped;
   st.gc_fitted = M.gc_fitted ? 1 : 0; st.insert_rate = M.insert_rate; st.del_rate = M.del_rate; st.std_isize = M.std_isize; st.gc_std = M.gc_std;
   st.t_total = since(t0);
 }

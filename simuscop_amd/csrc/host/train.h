@@ -23,11 +23,13 @@ typedef struct simu_train_options {
   int32_t threads;        // reader threads of the reference ingest
   int32_t quiet;          // no progress lines on stderr
   const char* stamp;      // NULL: the current time as saveResults prints it; tests pass a fixed line
+  uint64_t max_reads;     // --max-reads (additive): Profile::processRead's maxCount; 0 = the reference's 300,000,000 counted reads
+                          // (600,000,000 with targets), behind which it stops reading (Profile.cpp:236, 497-507)
 } simu_train_options;
 
 typedef struct simu_train_stats {
   uint64_t lines, reads_counted, gc_rejected, gc_windows, gc_pairs, skipped_overhang, sam_bytes;
-  int32_t read_length, bins, gc_fitted;
+  int32_t read_length, bins, gc_fitted, capped;   // capped: the run ended at max_reads
   double t_reference, t_reads, t_total;   // seconds: reference to the device; SAM text through the kernels; everything
   double insert_rate, del_rate, std_isize, gc_std;
 } simu_train_stats;

@@ -2,6 +2,7 @@
 // same options, same checks, same exit codes) over the GPU path of host/train.cpp.
 // Additive options the reference would reject:
 //   --sam <file|->   lines of `samtools view -F 0xD04 -q 20` text from a file or standard input (instead of running samtools)
+//   --max-reads <n>  Profile::processRead's cap on counted reads (default: the reference's 300,000,000; twice that with targets)
 //   --device <n>     GPU to use (default 0)        --quiet   no progress lines        --stats   one JSON line of counts and times
 #include <getopt.h>
 
@@ -27,7 +28,9 @@ static void usage(const char* app) {
             << "    -B, --bins <int>                the number of bins into which bases of read are grouped [default:50]\n"
             << "        --sam <file|->              (GPU build) reads as `samtools view` text from a file or standard input\n"
             << "        --device <int>              (GPU build) device to use [default:0]\n"
-            << "        --quiet                     (GPU build) no progress lines\n\n"
+            << "        --quiet                     (GPU build) no progress lines\n"
+            << "        --max-reads <int>           (GPU build) stop at so many counted reads [default: the reference's 300000000,\n"
+            << "                                    twice that with targets]\n\n"
             << "Example:\n"
             << "    " << app << " -b normal.bam -v normal.vcf -r ref.fa -o results.model -s /path/to/samtools\n"
             << "    samtools view -F 0xD04 -q 20 normal.bam | " << app << " --sam - -v normal.vcf -r ref.fa > results.model\n\n";
@@ -42,7 +45,7 @@ int main(int argc, char* argv[]) {
       {"help", no_argument, 0, 'h'},        {"bam", required_argument, 0, 'b'},    {"target", required_argument, 0, 't'},
       {"vcf", required_argument, 0, 'v'},   {"ref", required_argument, 0, 'r'},    {"output", required_argument, 0, 'o'},
       {"samtools", required_argument, 0, 's'}, {"kmer", required_argument, 0, 'k'}, {"bins", required_argument, 0, 'B'},
-      {"sam", required_argument, 0, 1000},  {"device", required_argument, 0, 1001}, {"quiet", no_argument, 0, 1002},   {"stats", no_argument, 0, 1003},
+      {"sam", required_argument, 0, 1000},  {"device", required_argument, 0, 1001}, {"quiet", no_argument, 0, 1002},   {"stats", no_argument, 0, 1003},      {"max-reads", required_argument, 0, 1004},
       {0, 0, 0, 0}};
   int c;
   while ((c = getopt_long(argc, argv, "hb:t:v:r:o:s:k:B:", long_options, NULL)) != -1) {
@@ -60,6 +63,7 @@ int main(int argc, char* argv[]) {
       case 1001: o.device = atoi(optarg); break;
       case 1002: o.quiet = 1; break;
       case 1003: stats = true; break;
+      case 1004: o.max_reads = strtoull(optarg, nullptr, 10); break;
       default: usage(argv[0]); return 1;
     }
   }
@@ -101,9 +105,9 @@ int main(int argc, char* argv[]) {
   }
   if (stats)
     fprintf(stderr, "{\"lines\": %llu, \"reads_counted\": %llu, \"gc_rejected\": %llu, \"gc_windows\": %llu, \"gc_pairs\": %llu, \"skipped_overhang\": %llu, "
-                    "\"sam_bytes\": %llu, \"read_length\": %d, \"bins\": %d, \"gc_fitted\": %d, \"t_reference\": %.4f, \"t_reads\": %.4f, \"t_total\": %.4f}\n",
+                    "\"sam_bytes\": %llu, \"read_length\": %d, \"bins\": %d, \"gc_fitted\": %d, \"capped\": %d, \"t_reference\": %.4f, \"t_reads\": %.4f, \"t_total\": %.4f}\n",
             (unsigned long long)st.lines, (unsigned long long)st.reads_counted, (unsigned long long)st.gc_rejected, (unsigned long long)st.gc_windows,
-            (unsigned long long)st.gc_pairs, (unsigned long long)st.skipped_overhang, (unsigned long long)st.sam_bytes, st.read_length, st.bins, st.gc_fitted,
+            (unsigned long long)st.gc_pairs, (unsigned long long)st.skipped_overhang, (unsigned long long)st.sam_bytes, st.read_length, st.bins, st.gc_fitted, st.capped,
             st.t_reference, st.t_reads, st.t_total);
   if (!o.quiet) {
     const long secs = (long)st.t_total;

@@ -783,6 +783,8 @@ int sg_load_profile(sg_ctx* ctx, const sg_profile_cdf* pr) {
 struct sg_train_session {
   char bases[4] = {0, 0, 0, 0};
   uint32_t kmer = 0, bins = 0, n_isize = 0, n_indel_len = 0, count_gc = 0, window = 1000, wes = 0, remap = 0;
+  uint64_t max_reads = 300000000;    // Profile.cpp:236
+  bool capped = false;               // the cap was reached: the reference has stopped reading
   uint32_t kc = 0, koff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   size_t subs_n = 0, kmers_n = 0, qual_n = 0, counters = 0;
   uint32_t n_contigs = 0;
@@ -854,6 +856,7 @@ int sg_train_begin(sg_ctx* ctx, const sg_train_setup* st) {
   memcpy(T->bases, st->bases, 4);
   T->kmer = (uint32_t)st->kmer; T->bins = (uint32_t)st->bins; T->n_isize = st->n_isize; T->n_indel_len = st->n_indel_len;
   T->count_gc = st->count_gc ? 1u : 0u; T->window = st->window; T->remap = remap; T->n_contigs = st->n_contigs;
+  if (st->max_reads) T->max_reads = st->max_reads;
   {
     uint32_t p4 = 1;
     for (int m = 1; m <= st->kmer; m++) { T->koff[m] = T->kc; p4 *= 4; T->kc += p4; }
@@ -1014,7 +1017,7 @@ void train_job(sg_ctx* ctx, sg_train_session* T, sg::TrainJob& J) {
   J.remap = T->remap;
   J.kmer = T->kmer; J.bins = T->bins; J.kmer_count = T->kc; J.n_isize = T->n_isize; J.n_indel_len = T->n_indel_len;
   for (int m = 0; m < 8; m++) J.kmer_off[m] = T->koff[m];
-  J.count_gc = T->count_gc; J.wes = T->wes; J.window = T->window;
+  J.count_gc = T->count_gc; J.wes = T->wes; J.window = T->window; J.max_reads = T->max_reads;
   J.tgt_left = T->tgt.as<int64_t>(); J.tgt_right = J.tgt_left + T->n_tgt; J.tgt_pmax = J.tgt_left + 2 * T->n_tgt;
   const int64_t* k64 = T->known.as<int64_t>();
   const int32_t* k32 = (const int32_t*)(T->known.as<uint8_t>() + (2 * T->n_ins + 2 * T->n_del) * 8);
@@ -1033,7 +1036,7 @@ int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
   if (!ctx || (sam_bytes && !sam_text)) return SG_ERR_INVALID;
   sg_train_session* T = ctx->train;
   if (!T) return ctx->fail(SG_ERR_INVALID, "sg_train_feed: call sg_train_begin first");
-  if (!sam_bytes) return SG_OK;
+  if (!sam_bytes || T->capped) return SG_OK;   // (behind the cap: Profile::train has left its loop, Profile.cpp:1461-1464)
   SG_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const bool open_end = sam_text[sam_bytes - 1] != '\n';   // a last line without a line break gets one in the device copy
@@ -1088,11 +1091,14 @@ int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
   SG_HIP(hipMemcpyAsync(&flags, T->flags.p, 4, hipMemcpyDeviceToHost, s));
   SG_HIP(hipStreamSynchronize(s));
   if (flags & 1u) return ctx->fail(SG_ERR_INVALID, "Error: malformed read , there should be 11 mandatory fields");   // Profile.cpp:246-251
-  T->lines += n_lines;
+  if (T->mail->cut_line != ~0ull) { T->capped = true; T->lines += T->mail->cut_line + 1; }
+  else T->lines += n_lines;
   if (T->count_gc) T->n_windows = T->mail->n_windows;
   T->cur ^= 1;
   return SG_OK;
 }
+
+int sg_train_capped(sg_ctx* ctx) { return ctx && ctx->train && ctx->train->capped ? 1 : 0; }
 
 int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, uint64_t gc_cap, uint64_t* n_gc) {
   if (!ctx || !out) return SG_ERR_INVALID;
@@ -1148,6 +1154,7 @@ int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, u
   out->skipped_overhang = sc[sg::kTrainOverhang];
   out->gc_rejected = sc[sg::kTrainGcRejected];
   out->gc_windows = nw;
+  out->capped = T->capped ? 1 : 0;
   sg_train_end(ctx);
   return SG_OK;
 }

@@ -23,7 +23,8 @@ struct TrainRead {    // one per line, written by train_fields_kernel
   int64_t pos0;       // POS - 1
   uint32_t len, cigar_len;
   uint32_t flags;     // 1 through the filters of :262-279 (countGC sees it), 2 tlen < 0 (mate 2, reverse-complemented), 4 quality
-                      // string as long as the read, 8 countGC returned non-zero, 16 a single nM inside its contig: counted
+                      // string as long as the read, 8 countGC returned non-zero, 16 a single nM inside its contig: counted,
+                      // 32 on X / Y / M, 64 starts behind its contig's end, 128 an empty line, 256 fewer than eleven fields
   int32_t tlen;
   uint32_t contig, pad;
 };
@@ -37,6 +38,8 @@ struct TrainCarry {
   uint32_t last_contig, has;     // contig of the last read countGC saw
   uint64_t n_windows;            // windows opened so far
   uint64_t n_lines, n_gated;     // of the chunk just processed (for the host)
+  uint64_t reads_total;          // reads counted so far (Profile::processRead's readCount)
+  uint64_t cut_line;             // the line of this chunk at which readCount reached its cap (:497-507), ~0: none
 };
 // known insertions / deletions of one kind, all contigs: file order for the prefix maxima, (pos, len) order for the look-up
 struct TrainKnown {
@@ -61,6 +64,7 @@ struct TrainJob {
   uint32_t kmer, bins, kmer_count, n_isize, n_indel_len;
   uint32_t kmer_off[8];        // first index of the contexts with m real bases
   uint32_t count_gc, wes, window;
+  uint64_t max_reads;          // Profile::processRead stops the run at so many counted reads (0: no cap)
   const int64_t* tgt_left;     // exome targets: first base, last base (0-based), running maximum of the last bases per contig
   const int64_t* tgt_right;
   const int64_t* tgt_pmax;

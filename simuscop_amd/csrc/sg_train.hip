@@ -11,8 +11,10 @@
 //                         running maximum therefore gives every read the state it finds, and with it the verdict the
 //                         reference reaches: turned away (behind the window), counted in it, or opening the next one
 //   window scan           windows opened so far -> the read's window; read counts by atomics (one per thread and window)
-//   train_cigar_kernel    lane = counted line: the CIGAR walk of :290-382 (insertion / deletion length counts unless the VCF
-//                         knows the event; only a single nM goes on)
+//   train_verdict_kernel  lane = line: will the read be counted (no hard clip, a single nM, inside its contig)?  Then a prefix
+//                         count of those reads finds the line at which Profile::processRead's cap ends the run (:497-507)
+//   train_effects_kernel  lane = line up to that one: the CIGAR walk of :290-382 (insertion / deletion length counts unless
+//                         the VCF knows the event), the counters of lines turned away
 //   train_count_lds_kernel  workgroup = a group of bins x a slice of the reads, sixteen lanes = read: subsDist1 / subsDist2 /
 //                         kmersDist (:399-442), qualityDist (:453-481) counted in LDS, added to memory once; iSizeDist
 //                         (:444-451).  (train_count_kernel: the same straight to memory, for tables that do not fit LDS)
@@ -156,7 +158,7 @@ struct LineOp {
   }
   __device__ void finish() const {}
   __device__ T carry_in() const { return 0; }
-  __device__ void carry_out(T total) const { J.carry_out->n_lines = total; }
+  __device__ void carry_out(T total) const { J.carry_out->n_lines = total; J.carry_out->cut_line = ~0ull; }
 };
 
 // ---- the reads countGC sees, compacted in file order ----
@@ -237,7 +239,7 @@ struct StateOp {
     if (!head) {
       window_of(C, excl.max_pos, ws, &l, &r, &none);
       if (g.pos0 < l) { J.steps[d] = S; return; }        // :552-554
-      if (g.pos0 <= r) { S.counted = 1; S.left = l; S.right = r; J.steps[d] = S; return; }   // :555-558
+      if (g.pos0 <= r) { S.counted = 1; S.left = l; S.right = r; J.steps[d] = S; J.reads[g.line].flags |= 8u; return; }   // :555-558
       open_now = true;
     }
     if (open_now) {
@@ -247,6 +249,7 @@ struct StateOp {
       if (none) S.pad = 1;
     }
     J.steps[d] = S;
+    if (S.counted) J.reads[g.line].flags |= 8u;
   }
   __device__ void finish() const {}
   __device__ T carry_in() const {
@@ -270,18 +273,17 @@ struct WindowOp {
   __device__ T identity() const { return 0; }
   __device__ uint64_t n() const { return J.carry_out->n_gated; }
   __device__ T combine(T a, T b) const { return a + b; }
-  __device__ T load(uint64_t d) const { return J.steps[d].opens; }
+  __device__ bool seen(uint64_t d) const { return (uint64_t)J.gate[d].line <= J.carry_out->cut_line; }   // (behind the cap: never read)
+  __device__ T load(uint64_t d) const { return seen(d) ? J.steps[d].opens : 0u; }
   __device__ void store(uint64_t d, T, T inc) {
+    if (!seen(d)) return;
     const TrainStep S = J.steps[d];
     const uint64_t id = inc - 1;     // (carry_in = the windows of the chunks before; a first read that opens nothing rides in
                                      //  their last window)
     if (S.opens) J.windows[id] = TrainWindow{S.left, S.right, J.gate[d].contig, S.pad ? 0u : S.ws};
     if (S.counted) {
-      J.reads[J.gate[d].line].flags |= 8u;
       if (id != cur) { finish(); cur = id; }
       cnt++;
-    } else {
-      atomicAdd(J.scalars + kTrainGcRejected, 1ull);
     }
   }
   __device__ void finish() {
@@ -290,6 +292,24 @@ struct WindowOp {
   }
   __device__ T carry_in() const { return J.carry_in->n_windows; }
   __device__ void carry_out(T total) const { J.carry_out->n_windows = total; }
+};
+
+// ---- Profile::processRead's cap: the run ends with the read that makes readCount reach maxCount (:497-507, :1461-1464);
+// nothing behind that line is ever read.  Prefix count of the reads that will be counted, over the lines of the chunk ----
+struct CutOp {
+  using T = uint64_t;
+  TrainJob J;
+  uint64_t limit;
+  __device__ T identity() const { return 0; }
+  __device__ uint64_t n() const { return J.n_lines; }
+  __device__ T combine(T a, T b) const { return a + b; }
+  __device__ T load(uint64_t i) const { return (J.reads[i].flags >> 4) & 1u; }
+  __device__ void store(uint64_t i, T excl, T inc) const {
+    if (inc == limit && excl + 1 == inc) J.carry_out->cut_line = i;
+  }
+  __device__ void finish() const {}
+  __device__ T carry_in() const { return J.carry_in->reads_total; }
+  __device__ void carry_out(T total) const { J.carry_out->reads_total = total; }
 };
 
 __device__ __forceinline__ bool is_digit(char c) { return c >= '0' && c <= '9'; }
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(256) void train_fields_kernel(TrainJob J) {
   const char* p = J.text + (li ? J.line_end[li - 1] + 1 : 0);
   const char* le = J.text + J.line_end[li];  // the line break
   auto done = [&]() { J.reads[li] = R; };
-  if (p == le) { atomicAdd(J.scalars + kTrainEmptyLines, 1ull); done(); return; }   // an empty line: processRead returns at once (:229-231)
+  if (p == le) { R.flags = 128u; done(); return; }   // an empty line: processRead returns at once (:229-231)
   // ---- the first eleven fields (:244-251) ----
   const char* fb[11];
   const char* fe[11];
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(256) void train_fields_kernel(TrainJob J) {
       a = q + 1;
     }
   }
-  if (nf < 11) { atomicOr(J.flags, 1u); done(); return; }
+  if (nf < 11) { R.flags = 256u; done(); return; }   // (an error, once the line is known to lie before the cap: train_effects_kernel)
   const long long position = field_int(fb[3], fe[3]);
   const int mapq = (int)field_int(fb[4], fe[4]);
   const int tlen = (int)field_int(fb[8], fe[8]);
@@ -364,10 +384,10 @@ __global__ __launch_bounds__(256) void train_fields_kernel(TrainJob J) {
   R.contig = (uint32_t)contig;
   R.flags = (tlen < 0 ? 2u : 0u) | ((uint32_t)(fe[10] - fb[10]) == slen ? 4u : 0u);
   if (J.count_gc) {
-    if (C.xym) { atomicAdd(J.scalars + kTrainGcRejected, 1ull); done(); return; }   // :532-535
+    if (C.xym) { R.flags |= 32u; done(); return; }   // :532-535
     // a read that starts behind its contig's end makes the reference throw (std::string::substr, Genome.cpp:435); one on an
     // empty contig never counts: both stay out of countGC's sight here
-    if (position - 1 < 0 || (uint64_t)(position - 1) >= C.length) { atomicAdd(J.scalars + kTrainOverhang, 1ull); done(); return; }
+    if (position - 1 < 0 || (uint64_t)(position - 1) >= C.length) { R.flags |= 64u; done(); return; }
     R.flags |= 1u;
   } else {
     R.flags |= 1u | 8u;   // (sg_train_count: every read through the filters is counted)
@@ -396,10 +416,38 @@ __device__ bool known_event(const TrainKnown& K, uint64_t first, uint32_t n, int
   return K.first[first + lo] < stop;
 }
 
-__global__ __launch_bounds__(256) void train_cigar_kernel(TrainJob J) {
+// Will the read reach Profile::processRead's `readCount++` (:483)?  The CIGAR walk without its counters: no hard clip, a
+// single nM, inside its contig.  (No side effect: which lines exist at all is only known once the cap has been applied.)
+__global__ __launch_bounds__(256) void train_verdict_kernel(TrainJob J) {
   const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= J.n_lines) return;
-  TrainRead R = J.reads[li];
+  const TrainRead R = J.reads[li];
+  if (!(R.flags & 8u)) return;
+  const char* cg = J.text + R.cigar_off;
+  const int n_c = (int)R.cigar_len;
+  int k = 0;
+  for (int i = 0; i < n_c; i++) {
+    const char c = cg[i];
+    if (is_digit(c)) { k++; continue; }
+    if (c == 'H') return;
+  }
+  if (n_c == 0 || k != n_c - 1 || cg[n_c - 1] != 'M') return;
+  const TrainContig C = J.contigs[R.contig];
+  if ((uint64_t)R.pos0 + R.len > C.length) return;
+  J.reads[li].ref_off = C.code_off + (uint64_t)R.pos0;
+  J.reads[li].flags = R.flags | 16u;
+}
+
+// Everything a line adds besides the count matrices, for the lines up to the cap: the counters of empty / turned-away /
+// overhanging lines, the error flag of a line with fewer than eleven fields, the CIGAR walk of :290-382.
+__global__ __launch_bounds__(256) void train_effects_kernel(TrainJob J) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= J.n_lines || li > J.carry_out->cut_line) return;
+  const TrainRead R = J.reads[li];
+  if (R.flags & 128u) { atomicAdd(J.scalars + kTrainEmptyLines, 1ull); return; }
+  if (R.flags & 256u) { atomicOr(J.flags, 1u); return; }
+  if (R.flags & 64u) { atomicAdd(J.scalars + kTrainOverhang, 1ull); return; }
+  if ((R.flags & 32u) || ((R.flags & 1u) && !(R.flags & 8u))) { atomicAdd(J.scalars + kTrainGcRejected, 1ull); return; }   // :283-285
   if (!(R.flags & 8u)) return;
   const TrainContig C = J.contigs[R.contig];
   // ---- CIGAR (:290-382) ----
@@ -435,10 +483,7 @@ __global__ __launch_bounds__(256) void train_cigar_kernel(TrainJob J) {
   }
   if (n_c == 0 || k != n_c - 1 || cg[n_c - 1] != 'M') return;   // :380-382
   // the reference indexes refSeq past its end when the read hangs over its contig (:458 with n = strlen(readSeq)): skipped
-  if ((uint64_t)R.pos0 + R.len > C.length) { atomicAdd(J.scalars + kTrainOverhang, 1ull); return; }
-  R.ref_off = C.code_off + (uint64_t)R.pos0;
-  J.reads[li].ref_off = R.ref_off;
-  J.reads[li].flags = R.flags | 16u;
+  if ((uint64_t)R.pos0 + R.len > C.length) atomicAdd(J.scalars + kTrainOverhang, 1ull);
 }
 
 // ---- the count matrices ----
@@ -532,7 +577,7 @@ __global__ __launch_bounds__(256) void train_count_kernel(TrainJob J) {
   GlobalSink sink{J};
   for (uint64_t li = wave; li < J.n_lines; li += n_waves) {
     const TrainRead R = J.reads[li];
-    if (!(R.flags & 16u)) continue;
+    if (!(R.flags & 16u) || li > J.carry_out->cut_line) continue;
     for (uint32_t i = lane; i < R.len; i += 64u) count_base(J, R, i, sink);
     if (lane == 0u) count_read_scalars(J, R);
   }
@@ -568,7 +613,7 @@ __global__ __launch_bounds__(256) void train_count_lds_kernel(TrainJob J, uint32
   const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15u;   // sixteen groups of sixteen lanes
   for (uint64_t li = r0 + sub; li < r1; li += 16u) {
     const TrainRead R = J.reads[li];
-    if (!(R.flags & 16u)) continue;
+    if (!(R.flags & 16u) || li > J.carry_out->cut_line) continue;
     const uint64_t n = R.len;
     // positions whose bin lies in [b0, b1): i * bins / n >= b0  <=>  i >= ceil(b0 n / bins)
     const uint32_t i_lo = (uint32_t)(((uint64_t)b0 * n + bins - 1u) / bins), i_hi = (uint32_t)(((uint64_t)b1 * n + bins - 1u) / bins);
@@ -650,13 +695,20 @@ void launch_train_lines_fill(const TrainJob& J, hipStream_t s) { run_scan_apply(
 
 void launch_train_chunk(const TrainJob& J, hipStream_t s) {
   if (!J.n_lines) return;
-  hipLaunchKernelGGL(train_fields_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
+  const dim3 per_line((uint32_t)((J.n_lines + 255) / 256));
+  hipLaunchKernelGGL(train_fields_kernel, per_line, dim3(256), 0, s, J);
   if (J.count_gc) {
     run_scan(GateOp{J}, J.n_lines, J.scan_work, s);
     run_scan(StateOp{J}, J.n_lines, J.scan_work, s);
-    run_scan(WindowOp{J}, J.n_lines, J.scan_work, s);
   }
-  hipLaunchKernelGGL(train_cigar_kernel, dim3((uint32_t)((J.n_lines + 255) / 256)), dim3(256), 0, s, J);
+  hipLaunchKernelGGL(train_verdict_kernel, per_line, dim3(256), 0, s, J);
+  {
+    // (always run: the carry's read count is what the host watches; without a cap no line can reach the limit)
+    const uint64_t limit = J.max_reads ? (J.wes ? 2 * J.max_reads : J.max_reads) : ~0ull;
+    run_scan(CutOp{J, limit}, J.n_lines, J.scan_work, s);
+  }
+  if (J.count_gc) run_scan(WindowOp{J}, J.n_lines, J.scan_work, s);
+  hipLaunchKernelGGL(train_effects_kernel, per_line, dim3(256), 0, s, J);
   // the count tables of as many bins as fit 60 KB of LDS; none do for kmer 6
   const uint32_t per_bin = (9u * J.kmer_count + 16u * 94u) * 4u;
   const uint32_t bpg = std::min<uint32_t>(J.bins, (60u << 10) / per_bin);

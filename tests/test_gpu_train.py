@@ -48,7 +48,7 @@ def _reference_on_device(eng, ctx, fasta_path, line_len=60):
 
 ARRAYS = ("subs1", "subs2", "kmers", "quality", "isize", "ins_len", "del_len")
 SCALARS = ("lines", "reads_counted", "cigar_chars", "insert_events", "delete_events", "isize_overflow", "indel_len_overflow", "skipped_overhang",
-           "gc_rejected", "gc_windows")
+           "gc_rejected", "gc_windows", "capped")
 
 
 def _same_counts(got, ga, want, wa):
@@ -128,7 +128,7 @@ def _setup_from_files(keys, lens, vcf, bed, T, keep):
     for line in open(vcf, "rb"):
         if line.startswith(b"#"):
             continue
-        f = line.rstrip(b"\n").split(b"\t")
+        f = line.split(b"\t")   # (the line break stays with the last field, as after fgets: "1/1\n" is not "1/1")
         if len(f) < 10:
             continue
         info = f[7]
@@ -469,3 +469,64 @@ def test_seqtoprofile_refusals(tmp_path):
     open(clipped, "wb").write(b"\n".join(l.replace(b"\t50M\t", b"\t5S45M\t") for l in good) + b"\n")
     r = run("--sam", clipped, "-v", vcf, "-r", fa, "-o", os.path.join(wd, "p2"))
     assert r.returncode == 1 and "single match" in r.stderr
+
+
+@pytest.mark.parametrize("exome", [False, True])
+def test_device_training_stops_at_the_cap(exome, oracle_lib, tmp_path):
+    """Profile::processRead's cap on counted reads (Profile.cpp:236, 497-507; twice it with targets) with small values: the
+    device cuts the chunk at the capping line -- counters, windows and pairs equal the restatement's, whether the line falls
+    in the first chunk, in a later one, or on a chunk's last line -- and ignores what is fed afterwards; the command line
+    stops reading and writes the restatement's file."""
+    import test_train_profile_cpu as TP
+    TP.declare(oracle_lib)
+    oracle_lib.orc_train_set_max_reads.argtypes = [C.c_uint64]
+    oracle_lib.orc_train_set_max_reads.restype = None
+    wd = str(tmp_path)
+    lines, fa1, T = _sampled_lines(oracle_lib, wd, coverage=4)
+    fa, vcf, bed, sam = TU.training_inputs(wd, fa1, lines, T.L, exome=exome)
+    eng = simuscop_amd.load_engine()
+    ends = [i + 1 for i, ch in enumerate(sam) if ch == 10]
+    cap_n = 200000
+    try:
+        for cap in ((100, 1, 400) if exome else (700, 1, 20011)):
+            oracle_lib.orc_train_set_max_reads(cap)
+            want, wa = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+            wgc, wrc, wn = (C.c_double * cap_n)(), (C.c_double * cap_n)(), C.c_uint64()
+            assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), (bed or "").encode(), T.bases.encode(), 3, T.bins, 2048, 256,
+                                        C.byref(want), wgc, wrc, cap_n, C.byref(wn)) == 0
+            assert want.capped == 1 and want.reads_counted == (2 * cap if exome else cap)
+            # chunk cuts: one exactly behind the capping line, one before it, a few behind it
+            at = ends[want.lines - 1]
+            for cuts in ([0, len(sam)], [0, at, len(sam)], sorted({0, ends[max(0, want.lines // 2)], at, ends[min(len(ends) - 1, want.lines + 5)], len(sam)})):
+                ctx = C.c_void_p()
+                assert eng.sg_create(C.byref(ctx), 0, 1) == 0
+                try:
+                    keys = _reference_on_device(eng, ctx, fa)
+                    lens = [len(b"".join(part.split(b"\n")[1:])) for part in open(fa, "rb").read().split(b">")[1:]]
+                    keep = []
+                    st = _setup_from_files(keys, lens, vcf, bed, T, keep)
+                    st.max_reads = cap
+                    assert eng.sg_train_begin(ctx, C.byref(st)) == 0, eng.sg_last_error(ctx)
+                    for a, b in zip(cuts, cuts[1:]):
+                        assert eng.sg_train_feed(ctx, sam[a:b], b - a) == 0, eng.sg_last_error(ctx)
+                    assert eng.sg_train_capped(ctx) == 1
+                    got, ga = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+                    ggc, grc, gn = (C.c_double * cap_n)(), (C.c_double * cap_n)(), C.c_uint64()
+                    assert eng.sg_train_finish(ctx, C.byref(got), ggc, grc, cap_n, C.byref(gn)) == 0, eng.sg_last_error(ctx)
+                    _same_counts(got, ga, want, wa)
+                    assert gn.value == wn.value and list(ggc[:gn.value]) == list(wgc[:wn.value]) and list(grc[:gn.value]) == list(wrc[:wn.value])
+                finally:
+                    eng.sg_destroy(ctx)
+        # the command line with --max-reads: the restatement's file
+        cli_cap = 300 if exome else 3000
+        oracle_lib.orc_train_set_max_reads(cli_cap)
+        sam_path, want_p, got_p = os.path.join(wd, "r.sam"), os.path.join(wd, "w.profile"), os.path.join(wd, "g.profile")
+        open(sam_path, "wb").write(sam)
+        assert oracle_lib.orc_train_profile(sam, len(sam), fa.encode(), vcf.encode(), (bed or "").encode(), b"ACTG", 3, 50, want_p.encode(), sam_path.encode(), b"stamp\n") == 0
+        exe = os.path.join(ROOT, "simuscop_amd", "lib", "seqToProfile")
+        r = subprocess.run([exe, "--sam", sam_path, "-v", vcf, "-r", fa, "-o", got_p, "--max-reads", str(cli_cap), "--quiet", "--stats"] + (["-t", bed] if bed else []),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and '"capped": 1' in r.stderr, r.stderr[-1500:]
+        assert open(want_p, "rb").read().split(b"\n", 1)[1] == open(got_p, "rb").read().split(b"\n", 1)[1]
+    finally:
+        oracle_lib.orc_train_set_max_reads(0)

@@ -126,3 +126,32 @@ def test_exome_targets_are_the_windows(trained, oracle_lib, tmp_path):
     gc, rc, n = (C.c_double * 100000)(), (C.c_double * 100000)(), C.c_uint64()
     assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), bed.encode(), T.bases.encode(), 3, T.bins, 2048, 256, C.byref(st), gc, rc, 100000, C.byref(n)) == 0
     assert 50 < n.value < 1000 and st.gc_rejected > st.reads_counted      # most reads lie between the targets
+
+
+def test_the_run_ends_at_the_cap_of_counted_reads(trained, oracle_lib):
+    """Profile::processRead returns 2 once `readCount` reaches `maxCount` (300,000,000; Profile.cpp:236, 497-507) and
+    Profile::train leaves its loop (:1461-1464): lines behind that read are never read.  With a small cap: exactly so many
+    reads counted, fewer lines seen, fewer windows; the text cut behind the capping line gives the same counters."""
+    T, sam, fa, vcf = trained["T"], trained["sam"], trained["fa"], trained["vcf"]
+    oracle_lib.orc_train_set_max_reads.argtypes = [C.c_uint64]
+    oracle_lib.orc_train_set_max_reads.restype = None
+    full, _ = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+    n = C.c_uint64()
+    assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), b"", T.bases.encode(), 3, T.bins, 2048, 256, C.byref(full), None, None, 0, C.byref(n)) == 0
+    assert full.capped == 0
+    try:
+        oracle_lib.orc_train_set_max_reads(5000)
+        cut, ca = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+        assert oracle_lib.orc_train(sam, len(sam), fa.encode(), vcf.encode(), b"", T.bases.encode(), 3, T.bins, 2048, 256, C.byref(cut), None, None, 0, C.byref(n)) == 0
+        assert cut.capped == 1 and cut.reads_counted == 5000 and cut.lines < full.lines and cut.gc_windows < full.gc_windows
+        # the same text without what lies behind the capping line: the same counters
+        lines = sam.split(b"\n")
+        part = b"\n".join(lines[:cut.lines]) + b"\n"
+        oracle_lib.orc_train_set_max_reads(0)
+        same, sa = TU.count_arrays(simuscop_amd.SgTrainCounts, T.kc, T.bins, 2048)
+        assert oracle_lib.orc_train(part, len(part), fa.encode(), vcf.encode(), b"", T.bases.encode(), 3, T.bins, 2048, 256, C.byref(same), None, None, 0, C.byref(n)) == 0
+        assert same.capped == 0 and same.reads_counted == 5000 and same.lines == cut.lines
+        for k in ca:
+            assert np.array_equal(ca[k], sa[k]), k
+    finally:
+        oracle_lib.orc_train_set_max_reads(0)
