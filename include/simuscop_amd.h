@@ -327,7 +327,10 @@ int sg_emit_info(sg_ctx* ctx, uint64_t* queued_items, int* requeued);
  * FASTA index does (first token, chr / chrom prefix stripped, Fasta.cpp:58-69).
  *   sg_train_begin   tables zeroed, targets and known variants staged (refSequence / altSequence of Genome.cpp:466-475)
  *   sg_train_feed    one chunk of WHOLE lines, in file order; state is carried from chunk to chunk (once the cap of
- *                    Profile::processRead has been reached, further chunks are ignored, as the reference stops reading)
+ *                    Profile::processRead has been reached, further chunks are ignored, as the reference stops reading).
+ *                    The text is copied before the call returns (the caller's buffer is free again); the chunk's kernels
+ *                    are left running, so its verdict -- SG_ERR_INVALID for a line with fewer than 11 fields
+ *                    (Profile.cpp:246-251), the cap -- is reported by the NEXT sg_train_feed or by sg_train_finish
  *   sg_train_finish  the count matrices; the (GC content, read count) pairs countGC pushed, in its order (gcs, readCounts)
  * Where the reference's behaviour is undefined the line is skipped and counted: reads hanging over their contig's end
  * (skipped_overhang).  Arrays are the caller's: subs1 / subs2 [kmer_count][bins][4], kmers [bins][kmer_count], quality
@@ -361,7 +364,8 @@ typedef struct sg_train_counts {
 } sg_train_counts;
 int sg_train_begin(sg_ctx* ctx, const sg_train_setup* setup);
 int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes);
-/* 1 once the cap on counted reads has been reached (the caller may stop reading its input), else 0 */
+/* 1 once the cap on counted reads is known to have been reached (the caller may stop reading its input), else 0; does not
+ * wait for the chunk in flight, whose verdict arrives with the next feed / finish (a chunk fed behind the cap is ignored) */
 int sg_train_capped(sg_ctx* ctx);
 /* gc / rc: room for `gc_cap` pairs (NULL: none wanted); *n_gc = how many there are (SG_ERR_OVERFLOW when gc_cap is too small;
  * call again).  The session ends with a successful call or with sg_train_end. */

@@ -521,6 +521,13 @@ void run(const simu_train_options& o, simu_train_stats& st) {
   S.n_ins = kv.ins_pos.size(); S.ins_contig = kv.ins_contig.data(); S.ins_pos = kv.ins_pos.data(); S.ins_len = kv.ins_len.data();
   S.n_del = kv.del_pos.size(); S.del_contig = kv.del_contig.data(); S.del_pos = kv.del_pos.data(); S.del_len = kv.del_len.data();
   eng.check(sg_train_begin(eng.ctx, &S), "sg_train_begin");
+  // (a chunk's verdict -- a malformed line, the cap -- is known when the next chunk is fed or at sg_train_finish)
+  auto engine_said = [&](int rc, const char* where) {
+    if (rc == SG_OK) return;
+    const std::string m = sg_last_error(eng.ctx);
+    if (rc == SG_ERR_INVALID && m.find("malformed read") != std::string::npos) throw Error(m, 1);
+    throw Error(std::string("GPU engine error in ") + where + ": " + m);
+  };
   while (have) {
     // the next chunk is read while the device works on this one
     bool more = false;
@@ -528,11 +535,7 @@ void run(const simu_train_options& o, simu_train_stats& st) {
     std::thread reader([&]() { try { more = rd->fill(cur ^ 1); } catch (const std::exception& e) { reader_error = e.what(); } });
     const int rc = sg_train_feed(eng.ctx, rd->buf[cur], rd->len[cur]);
     reader.join();
-    if (rc != SG_OK) {
-      const std::string m = sg_last_error(eng.ctx);
-      if (rc == SG_ERR_INVALID && m.find("malformed read") != std::string::npos) throw Error(m, 1);
-      throw Error("GPU engine error in sg_train_feed: " + m);
-    }
+    engine_said(rc, "sg_train_feed");
     if (!reader_error.empty()) throw Error(reader_error);
     st.sam_bytes += rd->len[cur];
     cur ^= 1;
@@ -551,9 +554,9 @@ void run(const simu_train_options& o, simu_train_stats& st) {
     (void)rcode;   // (gc_cap 0: the pairs are counted, the session stays open when there are any)
     if (rcode == SG_ERR_OVERFLOW) {
       M.gcs.resize(n_gc); M.rcs.resize(n_gc);
-      eng.check(sg_train_finish(eng.ctx, &C, M.gcs.data(), M.rcs.data(), n_gc, &n_gc), "sg_train_finish");
+      engine_said(sg_train_finish(eng.ctx, &C, M.gcs.data(), M.rcs.data(), n_gc, &n_gc), "sg_train_finish");
     } else {
-      eng.check(rcode, "sg_train_finish");
+      engine_said(rcode, "sg_train_finish");
     }
   }
   st.t_reads = since(t1);

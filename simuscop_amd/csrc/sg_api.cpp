@@ -788,17 +788,24 @@ struct sg_train_session {
   uint32_t kc = 0, koff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   size_t subs_n = 0, kmers_n = 0, qual_n = 0, counters = 0;
   uint32_t n_contigs = 0;
-  DevBuf keys, contigs, counts, flags, text, line_end, reads, gate, steps, windows, window_rc, carry, scan_work, tgt, known, t_ref, t_alt,
-      patch, gc_out;
+  DevBuf keys, contigs, counts, flags, text[2], line_end, reads, gate, steps, windows, window_rc, carry, scan_work, tgt, known, t_ref,
+      t_alt, patch, gc_out;
+  // Two text buffers and a copy stream: chunk k travels to text[k & 1] while the kernels of chunk k - 1 read the other one.
+  hipStream_t copy_stream = nullptr;
+  uint64_t fed = 0;                  // chunks handed to the kernels so far
+  bool pending = false;              // a chunk's kernels are queued whose carry / flags have not been looked at yet
+  uint64_t pending_lines = 0;
   bool own_codes = false;            // t_ref / t_alt are copies with the SNVs of the VCF in them
   uint64_t code_bytes = 0;
   uint64_t n_tgt = 0, n_ins = 0, n_del = 0;
   int cur = 0;                       // carry[cur] is read by the next chunk, carry[cur ^ 1] written
   uint64_t lines = 0, n_windows = 0; // lines fed / windows opened so far (host copies)
   uint64_t windows_cap = 0;          // rows the window arrays hold
-  sg::TrainCarry* mail = nullptr;    // pinned
+  sg::TrainCarry* mail = nullptr;    // pinned: the carry a chunk left, the flag word behind it
+  uint32_t* mail_flags() { return (uint32_t*)(mail + 1); }
   void release() {
-    for (DevBuf* b : {&keys, &contigs, &counts, &flags, &text, &line_end, &reads, &gate, &steps, &windows, &window_rc, &carry, &scan_work,
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+    for (DevBuf* b : {&keys, &contigs, &counts, &flags, &text[0], &text[1], &line_end, &reads, &gate, &steps, &windows, &window_rc, &carry, &scan_work,
                       &tgt, &known, &t_ref, &t_alt, &patch, &gc_out})
       b->release();
     if (mail) (void)hipHostFree(mail);
@@ -1000,7 +1007,8 @@ int sg_train_begin(sg_ctx* ctx, const sg_train_setup* st) {
   SG_HIP(hipMemsetAsync(T->counts.p, 0, T->counters * 8, s));
   SG_HIP(hipMemsetAsync(T->flags.p, 0, 64, s));
   SG_HIP(hipMemsetAsync(T->carry.p, 0, 2 * sizeof(sg::TrainCarry), s));
-  SG_HIP(hipHostMalloc((void**)&T->mail, sizeof(sg::TrainCarry), hipHostMallocDefault));
+  SG_HIP(hipHostMalloc((void**)&T->mail, sizeof(sg::TrainCarry) + 64, hipHostMallocDefault));
+  SG_HIP(hipStreamCreateWithFlags(&T->copy_stream, hipStreamNonBlocking));
   SG_HIP(hipStreamSynchronize(s));
   return SG_OK;
 }
@@ -1032,6 +1040,23 @@ void train_job(sg_ctx* ctx, sg_train_session* T, sg::TrainJob& J) {
 }
 }  // namespace
 
+namespace {
+// What the chunk whose kernels are queued left behind: the malformed-line flag, the cap, the windows opened so far.
+int train_settle(sg_ctx* ctx, sg_train_session* T) {
+  if (!T->pending) return SG_OK;
+  SG_HIP(hipStreamSynchronize(ctx->stream));
+  T->pending = false;
+  if (*T->mail_flags() & 1u) return ctx->fail(SG_ERR_INVALID, "Error: malformed read , there should be 11 mandatory fields");   // Profile.cpp:246-251
+  if (T->mail->cut_line != ~0ull) { T->capped = true; T->lines += T->mail->cut_line + 1; }
+  else T->lines += T->pending_lines;
+  if (T->count_gc) T->n_windows = T->mail->n_windows;
+  return SG_OK;
+}
+}  // namespace
+
+// One chunk of lines. The copy to the device runs on its own stream into the text buffer the previous chunk is not using, so it
+// overlaps that chunk's kernels; the call returns with its own kernels queued (sg_train_capped / the malformed-line error of
+// chunk k are known when chunk k + 1 is fed or sg_train_finish runs).
 int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
   if (!ctx || (sam_bytes && !sam_text)) return SG_ERR_INVALID;
   sg_train_session* T = ctx->train;
@@ -1041,13 +1066,18 @@ int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
   hipStream_t s = ctx->stream;
   const bool open_end = sam_text[sam_bytes - 1] != '\n';   // a last line without a line break gets one in the device copy
   const uint64_t bytes = sam_bytes + (open_end ? 1 : 0);
-  SG_ENSURE(T->text, bytes + 64);
-  SG_HIP(hipMemcpyAsync(T->text.p, sam_text, sam_bytes, hipMemcpyHostToDevice, s));
-  if (open_end) SG_HIP(hipMemsetAsync(T->text.as<char>() + sam_bytes, '\n', 1, s));
+  DevBuf& text = T->text[T->fed & 1];
+  SG_ENSURE(text, bytes + 64);
+  SG_HIP(hipMemcpyAsync(text.p, sam_text, sam_bytes, hipMemcpyHostToDevice, T->copy_stream));
+  if (open_end) SG_HIP(hipMemsetAsync(text.as<char>() + sam_bytes, '\n', 1, T->copy_stream));
+  int rc = train_settle(ctx, T);
+  SG_HIP(hipStreamSynchronize(T->copy_stream));   // the caller's buffer is free again when this returns
+  if (rc != SG_OK) return rc;
+  if (T->capped) return SG_OK;
   SG_ENSURE(T->scan_work, sg::train_scan_work_bytes(bytes / 64 + 1));
   sg::TrainJob J;
   train_job(ctx, T, J);
-  J.text = T->text.as<char>();
+  J.text = text.as<char>();
   J.bytes = bytes;
   J.scan_work = T->scan_work.p;
   sg::launch_train_lines_count(J, s);
@@ -1064,7 +1094,6 @@ int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
     const uint64_t want = T->n_windows + n_lines + 1;
     if (want > T->windows_cap) {
       const uint64_t cap = want + want / 2;
-      int rc;
       if ((rc = grow_keep(ctx, T->windows, T->n_windows * sizeof(sg::TrainWindow), cap * sizeof(sg::TrainWindow))) != SG_OK) return rc;
       if ((rc = grow_keep(ctx, T->window_rc, T->n_windows * 4, cap * 4)) != SG_OK) return rc;
       SG_HIP(hipMemsetAsync(T->window_rc.as<uint32_t>() + T->n_windows, 0, (cap - T->n_windows) * 4, s));
@@ -1086,18 +1115,17 @@ int sg_train_feed(sg_ctx* ctx, const char* sam_text, uint64_t sam_bytes) {
   sg::launch_train_lines_fill(J, s);
   sg::launch_train_chunk(J, s);
   SG_HIP(hipGetLastError());
-  uint32_t flags = 0;
   SG_HIP(hipMemcpyAsync(T->mail, J.carry_out, sizeof(sg::TrainCarry), hipMemcpyDeviceToHost, s));
-  SG_HIP(hipMemcpyAsync(&flags, T->flags.p, 4, hipMemcpyDeviceToHost, s));
-  SG_HIP(hipStreamSynchronize(s));
-  if (flags & 1u) return ctx->fail(SG_ERR_INVALID, "Error: malformed read , there should be 11 mandatory fields");   // Profile.cpp:246-251
-  if (T->mail->cut_line != ~0ull) { T->capped = true; T->lines += T->mail->cut_line + 1; }
-  else T->lines += n_lines;
-  if (T->count_gc) T->n_windows = T->mail->n_windows;
+  SG_HIP(hipMemcpyAsync(T->mail_flags(), T->flags.p, 4, hipMemcpyDeviceToHost, s));
+  T->pending = true;
+  T->pending_lines = n_lines;
   T->cur ^= 1;
+  T->fed++;
   return SG_OK;
 }
 
+// 1 once the cap on counted reads was reached. A chunk's verdict is known when the next one is fed (or at sg_train_finish):
+// a caller that stops feeding on it has handed over at most one chunk the reference would not have read, which is dropped.
 int sg_train_capped(sg_ctx* ctx) { return ctx && ctx->train && ctx->train->capped ? 1 : 0; }
 
 int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, uint64_t gc_cap, uint64_t* n_gc) {
@@ -1106,6 +1134,10 @@ int sg_train_finish(sg_ctx* ctx, sg_train_counts* out, double* gc, double* rc, u
   if (!T) return ctx->fail(SG_ERR_INVALID, "sg_train_finish: call sg_train_begin first");
   SG_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  {
+    const int settled = train_settle(ctx, T);
+    if (settled != SG_OK) return settled;
+  }
   // ---- the windows countGC pushed (Profile.cpp:559-570, 623-634): every window but the last one it was in, if its GC
   // content is above zero and it counted a read; in the order they were opened ----
   std::vector<double> h_gc, h_rc;
