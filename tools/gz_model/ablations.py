@@ -5,14 +5,18 @@ from tokens import len_sym, dist_sym, huff_lengths, acgt, CH, LANE
 from bits_by_line import line_types, evaluate, greedy
 
 def tokens3(m, probe_res=(0, 1), table_even=True, lane_tail=False, source="first", gram=8, min_copy=12, min_other=8, maxm=6, back_max=8,
-            tail_min=5, fixed_dist=False):
+            tail_min=5, fixed_dist=False, parts=1):
     n = len(m)
     first = {}
     step = 2 if table_even else 1
+    psize = (n + parts - 1) // parts
     for q in range(0, n - gram + 1, step):
         g = m[q:q + gram]
         if source == "first":
-            if g not in first: first[g] = [q]
+            if parts > 1:   # first occurrence inside every part of the member: up to `parts` candidates, the longest wins
+                lst = first.setdefault(g, [])
+                if not lst or lst[-1] // psize != q // psize: lst.append(q)
+            elif g not in first: first[g] = [q]
         else:
             first.setdefault(g, []).append(q)
     matches = []; cover = bytearray(n)
@@ -29,7 +33,16 @@ def tokens3(m, probe_res=(0, 1), table_even=True, lane_tail=False, source="first
             lst = first.get(g)
             cq = None
             if lst:
-                if source == "first":
+                if source == "first" and parts > 1:
+                    bestl = -1
+                    for cand in lst:
+                        if cand >= k: break
+                        l_ = 0
+                        while k + l_ < b and m[cand + l_] == m[k + l_]: l_ += 1
+                        bk = 0
+                        while bk < back_max and k - bk - 1 >= lo and cand - bk - 1 >= 0 and m[k - bk - 1] == m[cand - bk - 1]: bk += 1
+                        if l_ + bk >= bestl: bestl = l_ + bk; cq = cand
+                elif source == "first":
                     cq = lst[0] if lst[0] < k else None
                 else:
                     i = bisect.bisect_left(lst, k)
@@ -82,6 +95,11 @@ if __name__ == "__main__":
         "gram6": dict(gram=6, min_other=6),
         "gram6 lane_tail last": dict(gram=6, min_other=6, lane_tail=True, source="last"),
         "maxm 10": dict(maxm=10),
+        "parts2": dict(parts=2),
+        "parts4": dict(parts=4),
+        "parts8": dict(parts=8),
+        "parts4 + all probes": dict(parts=4, probe_res=(0, 1, 2, 3), table_even=False),
+        "parts16 + all probes": dict(parts=16, probe_res=(0, 1, 2, 3), table_even=False),
         "back 64": dict(back_max=64),
     }
     for k, v in V.items():
