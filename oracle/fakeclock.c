@@ -15,10 +15,18 @@
  * (Profile.cpp:1409-1415, one default_random_engine per GC%, each seeded from now()) all get the SAME seed and draw the
  * same sequence; the statistical tests of the GC law (tests/test_gpu_histograms.py) step the clock so that the reference
  * runs the way it does in the field.  The md5 pins keep the frozen clock.
+ *
+ * FAKECLOCK_NO_PIN (unset by default): the reference pins worker i to CPU i (ThreadPool.cpp:32-38); a test that starts
+ * several reference runs at once (the GC-law test: three runs of one work item each) would have them share CPU 0.  With
+ * the variable set pthread_setaffinity_np reports success without pinning and the scheduler places the workers.  What
+ * the reference computes does not depend on where its threads run.
  */
 #define _GNU_SOURCE
+#include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
+#include <dlfcn.h>
 #include <sys/time.h>
 
 static long fk_sec(void)  { const char *s = getenv("FAKECLOCK_SEC");  return s ? atol(s) : 1500000000L; }
@@ -45,4 +53,12 @@ int gettimeofday(struct timeval *tv, void *tz) {
   (void)tz;
   if (tv) { tv->tv_sec = fk_sec(); tv->tv_usec = fk_nsec() / 1000; }
   return 0;
+}
+
+int pthread_setaffinity_np(pthread_t th, size_t n, const cpu_set_t *set) {
+  typedef int (*fn_t)(pthread_t, size_t, const cpu_set_t *);
+  static fn_t real = 0;
+  if (getenv("FAKECLOCK_NO_PIN")) return 0;
+  if (!real) real = (fn_t)dlsym(RTLD_NEXT, "pthread_setaffinity_np");
+  return real ? real(th, n, set) : 0;
 }
