@@ -84,6 +84,10 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_philox4x32_r(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int orc_base_rounds(void);
 
+// Test utility (fastq_digest.cpp): count of the FASTQ records of the files and the sum of their 64-bit hashes -- equal for
+// two sets of files that hold the same records in any order.  0 on success, -1 unreadable file, -2 a file ends inside a record.
+int orc_fastq_record_digest(const char* const* paths, int n_paths, uint64_t* count, uint64_t* sum);
+
 #ifdef __cplusplus
 }
 #endif
