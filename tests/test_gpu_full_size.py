@@ -40,9 +40,13 @@ def _oracle_md5(oracle_lib, cfg, out_dir, seed):
     """FASTQ md5 sums of the oracle in Philox mode, threads = all host cores (results do not depend on the count)."""
     rc = oracle_lib.orc_simulate(cfg.encode(), 1, seed >> 32, seed & 0xFFFFFFFF, out_dir.encode(), os.cpu_count() or 1)
     assert rc == 0, oracle_lib.orc_last_error().decode()
+    from concurrent.futures import ThreadPoolExecutor
+    names = sorted(os.listdir(out_dir))
+    with ThreadPoolExecutor(max_workers=2) as pool:   # (hashlib releases the GIL: the mates' digests side by side)
+        sums = list(pool.map(lambda f: _md5_file(os.path.join(out_dir, f)), names))
     out = {}
-    for f in sorted(os.listdir(out_dir)):
-        out[f] = (_md5_file(os.path.join(out_dir, f)), os.path.getsize(os.path.join(out_dir, f)))
+    for f, m in zip(names, sums):
+        out[f] = (m, os.path.getsize(os.path.join(out_dir, f)))
         os.remove(os.path.join(out_dir, f))   # gigabytes each
     return out
 
