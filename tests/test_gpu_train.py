@@ -473,6 +473,54 @@ def test_seqtoprofile_refusals(tmp_path):
     assert r.returncode == 1 and "single match" in r.stderr
 
 
+def test_a_chunks_verdict_arrives_with_the_next_call(tmp_path):
+    """sg_train_feed returns with the chunk's kernels running: a line with fewer than eleven fields (Profile.cpp:246-251)
+    in chunk k is reported by the feed of chunk k + 1, or by sg_train_finish when it was the last chunk -- with the
+    reference's message either way -- and the caller's buffer may be reused as soon as feed has returned."""
+    import random
+    import ctypes
+    from simuscop_amd import synth
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "r.fa")
+    seq = synth.synth_contig(6000, 5, 0, n_runs=False).tobytes()
+    open(fa, "wb").write(b">chr1\n" + b"".join(seq[i:i + 60] + b"\n" for i in range(0, len(seq), 60)))
+    vcf = os.path.join(wd, "k.vcf")
+    open(vcf, "w").write("##fileformat=VCFv4.2\n")
+    rng = random.Random(5)
+    good = [TU._crafted(rng, b"chr1", seq, p, 50, 200) for p in range(1, 5000, 5)]
+    ok = b"\n".join(good[:400]) + b"\n"
+    bad = b"\n".join(good[400:500] + [b"r\t0\tchr1\t10\t60"] + good[500:600]) + b"\n"
+    tail = b"\n".join(good[600:]) + b"\n"
+    eng = simuscop_amd.load_engine()
+
+    class TT:
+        bases, bins = "ACTG", 10
+    for chunks, failing_call in (((ok, bad, tail), 2), ((ok, bad), "finish")):
+        ctx = C.c_void_p()
+        assert eng.sg_create(C.byref(ctx), 0, 1) == 0
+        try:
+            keys = _reference_on_device(eng, ctx, fa)
+            keep = []
+            st = _setup_from_files(keys, [len(seq)], vcf, None, TT, keep)
+            assert eng.sg_train_begin(ctx, C.byref(st)) == 0, eng.sg_last_error(ctx)
+            buf = ctypes.create_string_buffer(max(len(c) for c in chunks))   # ONE buffer for every chunk, rewritten right after feed
+            for i, c in enumerate(chunks):
+                ctypes.memmove(buf, c, len(c))
+                rc = eng.sg_train_feed(ctx, buf, len(c))
+                ctypes.memset(buf, 0x41, len(buf))
+                if i == failing_call:
+                    assert rc != 0 and b"malformed read" in eng.sg_last_error(ctx) and b"11 mandatory fields" in eng.sg_last_error(ctx)
+                    break
+                assert rc == 0, (i, eng.sg_last_error(ctx))
+            else:
+                got, ga = TU.count_arrays(simuscop_amd.SgTrainCounts, 84, 10, 2048)
+                rc = eng.sg_train_finish(ctx, C.byref(got), None, None, 0, C.byref(C.c_uint64()))
+                assert failing_call == "finish" and rc != 0 and b"malformed read" in eng.sg_last_error(ctx)
+        finally:
+            eng.sg_train_end(ctx)
+            eng.sg_destroy(ctx)
+
+
 @pytest.mark.parametrize("exome", [False, True])
 def test_device_training_stops_at_the_cap(exome, oracle_lib, tmp_path):
     """Profile::processRead's cap on counted reads (Profile.cpp:236, 497-507; twice it with targets) with small values: the
