@@ -92,7 +92,8 @@ def test_device_counts_equal_the_restatement(profile, insert, oracle_lib, tmp_pa
         bad = b"r0\t0\tchr1\t100\t60\n"
         assert eng.sg_train_count(ctx, bad, len(bad), karr, len(keys), T.bases.encode(), 3, T.bins, 1024, 256, C.byref(got)) != 0
         # other base orders / context lengths (the kernel's context index against the restatement's trie)
-        for bases, kmer in ((b"ACGT", 2), (b"GTCA", 4)):
+        # (1 .. 6: the ABI's whole range; from five bases on the count tables leave LDS for global atomics)
+        for bases, kmer in ((b"ACTG", 1), (b"ACGT", 2), (b"GTCA", 4), (b"TGCA", 5), (b"CATG", 6)):
             kc = sum(4 ** m for m in range(1, kmer + 1))
             w2, wa2 = TU.count_arrays(simuscop_amd.SgTrainCounts, kc, 20, 1024)
             g2, ga2 = TU.count_arrays(simuscop_amd.SgTrainCounts, kc, 20, 1024)
